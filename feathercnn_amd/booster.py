@@ -1,0 +1,204 @@
+"""Python host-side mirror of the reference operator interface for the conv hot path.
+
+Same names, argument meaning and error behaviour as ``booster::ConvParam`` / ``booster::ConvBooster``
+(reference src/booster/include/booster/booster.h:59-170, src/booster/avx/booster.cpp:283-355) and the caller
+contract of ``feather::ConvLayer`` (reference src/layers/conv_layer.h:92-172), so the parity tests read like
+code written against the reference.  Tensors are torch CUDA tensors (device memory + stream plumbing only);
+every call goes through the C-ABI of ``libfeather_hip.so``.  No fallback path exists.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+from . import _lib
+
+# booster::ConvAlgo (booster.h:42-51)
+NAIVE, IM2COL, SGECONV, DEPTHWISE, WINOGRADF63, WINOGRADF63FUSED, WINOGRADF23 = range(7)
+ALGO_NAMES = {NAIVE: "NAIVE", IM2COL: "IM2COL", SGECONV: "SGECONV", DEPTHWISE: "DEPTHWISE", WINOGRADF63: "WINOGRADF63",
+              WINOGRADF63FUSED: "WINOGRADF63FUSED", WINOGRADF23: "WINOGRADF23"}
+# booster::ActivationType (booster.h:53-57); `None` is a Python keyword, hence None_
+None_, ReLU = 0, 1
+
+
+class FeatherHipError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = _lib.load_library().fhip_last_error().decode(errors="replace")
+        raise FeatherHipError(f"{what} failed with code {rc}: {msg}")
+
+
+@dataclass
+class ConvParam:
+    """booster::ConvParam (booster.h:59-77) + the GPU-side ``batch`` extension (0/1 = the reference's N=1)."""
+    output_channels: int = 0
+    input_channels: int = 0
+    input_h: int = 0
+    input_w: int = 0
+    kernel_h: int = 0
+    kernel_w: int = 0
+    output_h: int = 0
+    output_w: int = 0
+    stride_h: int = 0
+    stride_w: int = 0
+    pad_left: int = 0
+    pad_bottom: int = 0
+    pad_right: int = 0
+    pad_top: int = 0
+    group: int = 0
+    bias_term: bool = False
+    activation: int = None_
+    batch: int = 1
+
+    def _c(self) -> _lib.fhip_conv_param:
+        return _lib.fhip_conv_param(self.output_channels, self.input_channels, self.input_h, self.input_w, self.kernel_h,
+                                    self.kernel_w, self.output_h, self.output_w, self.stride_h, self.stride_w,
+                                    self.pad_left, self.pad_bottom, self.pad_right, self.pad_top, self.group,
+                                    1 if self.bias_term else 0, int(self.activation))
+
+    def AssignOutputDim(self):
+        """ConvParam::AssignOutputDim (booster.h:113-125), computed by the library so host and device agree."""
+        c = self._c()
+        _check(_lib.load_library().fhip_conv_assign_output_dim(ctypes.byref(c)), "fhip_conv_assign_output_dim")
+        self.group, self.stride_h, self.stride_w = c.group, c.stride_h, c.stride_w
+        self.output_h, self.output_w, self.output_channels = c.output_h, c.output_w, c.output_channels
+
+    def GetFLOPS(self) -> float:
+        """ConvParam::GetFLOPS (booster.h:145-148), per image."""
+        c = self._c()
+        return _lib.load_library().fhip_conv_flops(ctypes.byref(c))
+
+    @staticmethod
+    def make(ic, oc, h, k=3, s=1, p=0, group=1, bias=True, act=ReLU, w=None, batch=1) -> "ConvParam":
+        q = ConvParam(output_channels=oc, input_channels=ic, input_h=h, input_w=h if w is None else w, kernel_h=k,
+                      kernel_w=k, stride_h=s, stride_w=s, pad_left=p, pad_bottom=p, pad_right=p, pad_top=p, group=group,
+                      bias_term=bool(bias), activation=act, batch=batch)
+        q.AssignOutputDim()
+        return q
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise FeatherHipError("feathercnn_amd needs device tensors (there is no CPU path)")
+    if not t.is_contiguous():
+        raise FeatherHipError("tensors must be dense NCHW")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ConvBooster:
+    """booster::ConvBooster (booster.h:156-170).  Does not allocate: the caller owns every tensor."""
+
+    def __init__(self):
+        self.algo = None
+
+    def SelectAlgo(self, param: ConvParam) -> int:
+        """avx/booster.cpp:283-310.  Returns 0, or -1 for partial groups (callers may ignore it, as ConvLayer does)."""
+        a = ctypes.c_int(-1)
+        c = param._c()
+        rc = _lib.load_library().fhip_conv_select_algo(ctypes.byref(c), ctypes.byref(a))
+        if rc != 0:
+            self.algo = None
+            return -1
+        self.algo = a.value
+        return 0
+
+    def ForceSelectAlgo(self, algo: int) -> int:
+        """avx/booster.cpp:313-317 + SetFuncs :319-355: -1 and no bound functions for unsupported algos."""
+        if algo not in (NAIVE, IM2COL, DEPTHWISE, WINOGRADF63):
+            self.algo = None
+            return -1
+        self.algo = algo
+        return 0
+
+    def _need_algo(self):
+        if self.algo is None:
+            raise FeatherHipError("no algorithm bound (SelectAlgo / ForceSelectAlgo returned -1)")
+
+    def GetBufferSize(self, param: ConvParam):
+        """GET_BUFFER_SIZE_FUNC: returns (buffer_bytes, processed_kernel_bytes) for param.batch images."""
+        self._need_algo()
+        b, k = ctypes.c_size_t(), ctypes.c_size_t()
+        c = param._c()
+        _check(_lib.load_library().fhip_conv_get_buffer_size(ctypes.byref(c), self.algo, max(param.batch, 1), ctypes.byref(b),
+                                                            ctypes.byref(k)), "fhip_conv_get_buffer_size")
+        return b.value, k.value
+
+    def Init(self, param: ConvParam, processed_kernel, kernel) -> int:
+        """INIT_FUNC: one-time weight pre-processing on the device."""
+        self._need_algo()
+        c = param._c()
+        _check(_lib.load_library().fhip_conv_init(ctypes.byref(c), self.algo, _ptr(processed_kernel), _ptr(kernel), _stream()),
+               "fhip_conv_init")
+        return 0
+
+    def Forward(self, param: ConvParam, output, input, processed_kernel, buffer, bias_arr, num_threads: int = 1) -> int:
+        """FORWARD_FUNC; num_threads is accepted and ignored."""
+        self._need_algo()
+        c = param._c()
+        _check(_lib.load_library().fhip_conv_forward(ctypes.byref(c), self.algo, max(param.batch, 1), _ptr(output), _ptr(input),
+                                                    _ptr(processed_kernel), _ptr(buffer), _ptr(bias_arr), _stream()),
+               "fhip_conv_forward")
+        return 0
+
+
+class ConvLayer:
+    """The caller side of the boundary, after feather::ConvLayer (reference src/layers/conv_layer.h:92-172):
+    Reshape (AssignOutputDim + SelectAlgo + GetBufferSize), Init once (packed weights replace raw weights),
+    Forward per batch.  The scratch arena is handed in by the owner, like CommonMemPool (mempool.cpp:88-109)."""
+
+    def __init__(self, param: ConvParam, weight, bias=None, algo: int | None = None):
+        import torch
+        self.param = param
+        self.param.AssignOutputDim()
+        self.booster = ConvBooster()
+        rc = self.booster.SelectAlgo(param) if algo is None else self.booster.ForceSelectAlgo(algo)
+        if rc != 0:
+            raise FeatherHipError("unsupported convolution (partial group or algo)")
+        self.buffer_bytes, self.packed_bytes = self.booster.GetBufferSize(param)
+        self.bias = bias
+        self.packed = torch.empty(max(self.packed_bytes // 4, 1), dtype=torch.float32, device=weight.device)
+        self.booster.Init(param, self.packed, weight.contiguous())
+
+    def out_shape(self):
+        p = self.param
+        return (max(p.batch, 1), p.output_channels, p.output_h, p.output_w)
+
+    def Forward(self, x, out=None, scratch=None):
+        import torch
+        if out is None:
+            out = torch.empty(self.out_shape(), dtype=torch.float32, device=x.device)
+        if scratch is None and self.buffer_bytes:
+            scratch = torch.empty(self.buffer_bytes // 4, dtype=torch.float32, device=x.device)
+        self.booster.Forward(self.param, out, x, self.packed, scratch, self.bias)
+        return out
+
+
+def stage_timing(enable: bool):
+    _check(_lib.load_library().fhip_stage_timing_enable(1 if enable else 0), "fhip_stage_timing_enable")
+
+
+def stage_timing_collect():
+    """-> {stage_name: (total_ms, launches)} since the last collect."""
+    n = len(_lib.STAGE_NAMES)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_longlong * n)()
+    _check(_lib.load_library().fhip_stage_timing_collect(ms, cnt), "fhip_stage_timing_collect")
+    return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.STAGE_NAMES)}
+
+
+def winograd_plan(param: ConvParam):
+    pl = _lib.fhip_winograd_plan()
+    c = param._c()
+    _check(_lib.load_library().fhip_winograd_f63_plan(ctypes.byref(c), max(param.batch, 1), ctypes.byref(pl)),
+           "fhip_winograd_f63_plan")
+    return pl

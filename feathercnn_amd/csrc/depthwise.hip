@@ -1,0 +1,214 @@
+// depthwise.hip -- depthwise convolution (group == input_channels) for gfx950.
+// Replaces DEPTHWISE_GetBufferSize/Init/Forward (reference src/booster/avx/booster.cpp:121-160):
+// pad_input (avx/generic_kernels.cpp:31-48) + dwConv_template<bias,relu> (avx/depthwise.cpp:161-207, incl. the
+// global-kernel case :30-54).  Same arithmetic -- per-channel 2-D correlation, taps accumulated in (m, n) order
+// in fp32, + bias[c], ReLU, floor output dims -- but no padded copy of the input: padding is a bounds check.
+//
+// This is an HBM-bound kernel (9 FMA per 8 bytes moved): the whole job is to move each input and output
+// element once, in 16-byte coalesced accesses.  Fast path (3x3, stride 1 or 2, the MobileNet shapes):
+//   * the NCHW tensor is a flat run of (n,c) planes, so a block takes a CHUNK of consecutive whole planes
+//     (as many as fit the LDS budget) and copies it global->LDS with straight float4 loads -- perfectly
+//     coalesced, no halo re-reads, no per-row address math;
+//   * every lane then produces 4 consecutive outputs of one row from three 16-byte LDS reads per input row
+//     (conflict-free ds_read_b128; the left/right halo taps come from the neighbouring aligned quads) and
+//     writes them with one float4 store -- output planes of a chunk are contiguous too.
+// Everything else (other kernel sizes, strides, widths not divisible by 4, planes larger than LDS, the
+// global-kernel case) goes through a generic one-output-per-lane kernel.
+#include "common.h"
+
+namespace fhip
+{
+
+struct DwParams
+{
+    const float* in;
+    const float* w;
+    const float* bias;
+    float* out;
+    int C, H, W, OH, OW, KH, KW, SH, SW, PL, PT;
+    int planes;           // N*C
+    int planes_per_chunk; // fast path
+    int has_bias, relu;
+};
+
+constexpr int kDwLdsFloats = 14336; // 56 KiB of plane data per block (+ weights) -> 2 blocks per CU
+
+template <int S>
+__global__ __launch_bounds__(256) void depthwise3x3_lds_kernel(const DwParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = q.H * q.W, OHW = q.OH * q.OW;
+    float* tile = smem;                                  // [planes_per_chunk][H][W]
+    float* wl = smem + (size_t)q.planes_per_chunk * HW;  // [planes_per_chunk][12]: 9 taps, bias, pad
+    const int tid = threadIdx.x;
+    const int chunks = (q.planes + q.planes_per_chunk - 1) / q.planes_per_chunk;
+    const int ow4 = q.OW >> 2, groups_per_plane = OHW >> 2;
+
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
+    {
+        const int plane0 = chunk * q.planes_per_chunk;
+        const int np = min(q.planes_per_chunk, q.planes - plane0);
+        // ---- stage: global -> LDS, 16 B per lane, fully coalesced -----------------------------------
+        {
+            const float4* src = reinterpret_cast<const float4*>(q.in + (size_t)plane0 * HW);
+            float4* dst = reinterpret_cast<float4*>(tile);
+            const int n4 = (np * HW) >> 2;
+            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+            for (int i = tid; i < np * 12; i += 256)
+            {
+                const int pl = i / 12, e = i - pl * 12;
+                const int c = (plane0 + pl) % q.C;
+                float v = 0.f;
+                if (e < 9) v = q.w[c * 9 + e];
+                else if (e == 9 && q.has_bias) v = q.bias[c];
+                wl[i] = v;
+            }
+        }
+        __syncthreads();
+        // ---- compute: 4 outputs of one row per lane -------------------------------------------------
+        const int ngroups = np * groups_per_plane;
+        float4* obase = reinterpret_cast<float4*>(q.out + (size_t)plane0 * OHW);
+        for (int gi = tid; gi < ngroups; gi += 256)
+        {
+            const int pl = gi / groups_per_plane, r = gi - pl * groups_per_plane;
+            const int oy = r / ow4, ox0 = (r - oy * ow4) << 2;
+            const float* wp = wl + pl * 12;
+            const float* ip = tile + (size_t)pl * HW;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const int xb = ox0 * S; // first aligned quad of the taps; taps span [xb-1, xb+4*S]
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+            {
+                const int y = oy * S - q.PT + m;
+                if ((unsigned)y >= (unsigned)q.H) continue;
+                const float* row = ip + y * q.W;
+                // x[j] holds input column xb - 1 + j
+                float x[4 * S + 3];
+                {
+                    const int xl = xb - 4;
+                    const float4 L = *reinterpret_cast<const float4*>(row + max(xl, 0));
+                    x[0] = xl >= 0 ? L.w : 0.f;
+                }
+#pragma unroll
+                for (int qd = 0; qd < S; ++qd)
+                {
+                    const float4 Cq = *reinterpret_cast<const float4*>(row + xb + 4 * qd); // always inside the row
+                    x[1 + 4 * qd] = Cq.x;
+                    x[2 + 4 * qd] = Cq.y;
+                    x[3 + 4 * qd] = Cq.z;
+                    x[4 + 4 * qd] = Cq.w;
+                }
+                {
+                    const int xr = xb + 4 * S;
+                    const bool ok = xr < q.W;
+                    const float4 R = *reinterpret_cast<const float4*>(row + (ok ? xr : q.W - 4));
+                    x[4 * S + 1] = ok ? R.x : 0.f;
+                    if (S == 2) x[4 * S + 2] = ok ? R.y : 0.f; // never used by a tap; keeps the array dense
+                }
+                const float w0 = wp[m * 3 + 0], w1 = wp[m * 3 + 1], w2 = wp[m * 3 + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    acc[e] += x[e * S + 0] * w0;
+                    acc[e] += x[e * S + 1] * w1;
+                    acc[e] += x[e * S + 2] * w2;
+                }
+            }
+            const float b = wp[9];
+            float4 o;
+            o.x = apply_act(acc[0] + b, q.relu);
+            o.y = apply_act(acc[1] + b, q.relu);
+            o.z = apply_act(acc[2] + b, q.relu);
+            o.w = apply_act(acc[3] + b, q.relu);
+            obase[gi] = o;
+        }
+        __syncthreads();
+    }
+}
+
+// Generic path: one output per lane, lanes along the flattened (plane, oy, ox) index.
+__global__ __launch_bounds__(256) void depthwise_generic_kernel(const DwParams q, long long total)
+{
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    {
+        const int plane = (int)(idx / OHW), r = (int)(idx - (long long)plane * OHW);
+        const int oy = r / q.OW, ox = r - oy * q.OW;
+        const int c = plane % q.C;
+        const float* ip = q.in + (size_t)plane * HW;
+        const float* wp = q.w + (size_t)c * q.KH * q.KW;
+        float s = 0.f;
+        for (int m = 0; m < q.KH; ++m)
+        {
+            const int y = oy * q.SH - q.PT + m;
+            if ((unsigned)y >= (unsigned)q.H) continue;
+            for (int n = 0; n < q.KW; ++n)
+            {
+                const int x = ox * q.SW - q.PL + n;
+                if ((unsigned)x >= (unsigned)q.W) continue;
+                s += ip[y * q.W + x] * wp[m * q.KW + n];
+            }
+        }
+        if (q.has_bias) s += q.bias[c];
+        q.out[idx] = apply_act(s, q.relu);
+    }
+}
+
+int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* kernel, const float* bias,
+                      hipStream_t s)
+{
+    if (p.group != p.input_channels) return fail(FHIP_E_UNSUPPORTED, "depthwise needs group == input_channels");
+    if (batch < 1) return fail(FHIP_E_BADARG, "batch < 1");
+    if (p.bias_term && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    DwParams q;
+    q.in = in;
+    q.w = kernel;
+    q.bias = bias;
+    q.out = out;
+    q.C = p.input_channels;
+    q.H = p.input_h;
+    q.W = p.input_w;
+    q.OH = p.output_h;
+    q.OW = p.output_w;
+    q.KH = p.kernel_h;
+    q.KW = p.kernel_w;
+    q.SH = p.stride_h > 0 ? p.stride_h : 1;
+    q.SW = p.stride_w > 0 ? p.stride_w : 1;
+    q.PL = p.pad_left;
+    q.PT = p.pad_top;
+    const long long planes = (long long)batch * q.C;
+    if (planes > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N*C too large");
+    q.planes = (int)planes;
+    q.has_bias = p.bias_term != 0;
+    q.relu = p.activation == FHIP_ACT_RELU;
+    q.planes_per_chunk = 0;
+    if (q.OH < 1 || q.OW < 1) return fail(FHIP_E_BADARG, "empty output");
+
+    const int HW = q.H * q.W;
+    // the right-halo quad of the last group starts at (OW-4)*S + 4*S = OW*S: it is either inside the row or fully
+    // outside (zero); the centre quads need OW*S <= W.
+    const bool fast = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1 && (q.W % 4) == 0 &&
+                      (q.OW % 4) == 0 && q.OW * q.SW <= q.W && q.W >= 4 && HW + 12 <= kDwLdsFloats;
+    StageTimer tm(FHIP_STAGE_DEPTHWISE, s);
+    if (fast)
+    {
+        q.planes_per_chunk = min(q.planes, kDwLdsFloats / (HW + 12));
+        const int chunks = ceil_div(q.planes, q.planes_per_chunk);
+        const size_t lds = (size_t)q.planes_per_chunk * (HW + 12) * sizeof(float);
+        const int grid = min(chunks, 256 * 8);
+        if (q.SH == 1)
+            hipLaunchKernelGGL(depthwise3x3_lds_kernel<1>, dim3(grid), dim3(256), lds, s, q);
+        else
+            hipLaunchKernelGGL(depthwise3x3_lds_kernel<2>, dim3(grid), dim3(256), lds, s, q);
+    }
+    else
+    {
+        const long long total = planes * q.OH * q.OW;
+        const int grid = (int)min((long long)256 * 16, (total + 255) / 256);
+        hipLaunchKernelGGL(depthwise_generic_kernel, dim3(grid), dim3(256), 0, s, q, total);
+    }
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+} // namespace fhip

@@ -1,0 +1,250 @@
+// implicit_gemm.hip -- the IM2COL route of ConvBooster on gfx950 as an implicit GEMM:
+//   out[K x (N*Ho*Wo)] = W[K x C*kh*kw] * col,   col[(c,u,v)][(n,oy,ox)] = in[n][c][oy*sh+u-pt][ox*sw+v-pl] or 0
+// Replaces IM2COL_GetBufferSize/Init/Forward (reference src/booster/avx/booster.cpp:64-102): booster::im2col
+// (avx/generic_kernels.cpp:50-85) is never materialised -- the B-operand loader of gemm_core.h gathers the
+// column matrix straight from the NCHW input into LDS (zero for out-of-bounds taps, same rule as :66-69) --
+// and packed_sgemm_init / packed_sgemm_activation<bias,relu> (avx/sgemm.cpp:312-433) become a transposed,
+// zero-padded weight panel Wt[Cp*kh*kw][Kp] plus the shared fp32-MFMA main loop with the bias / ReLU
+// epilogue fused into the accumulator store.  It serves exactly what AVX SelectAlgo routes to IM2COL
+// (avx/booster.cpp:294-303): 1x1 s1/s2, 7x7 s2, 3x3 with H <= 8 or C % 4 != 0, 3x3 s2; and NAIVE
+// (avx/booster.cpp:28-61, which ignores activation).
+#include "gemm_core.h"
+
+namespace fhip
+{
+
+struct ConvGemmParams
+{
+    int batches, m_tiles, n_tiles, k_tiles;
+    const float* Wt;
+    const float* in;
+    float* out;
+    const float* bias;
+    int C, K, H, W, OH, OW, SH, SW, PL, PT, KH, KW;
+    int Kd;   // C*KH*KW
+    int Kp;   // padded output channels = row stride of Wt
+    int Ntot; // N*OH*OW
+    int OHW, HW, KHW;
+    int has_bias, relu;
+};
+
+// MODE 0: generic gather (any kernel / stride / pad)
+// MODE 1: 1x1, pad 0, any stride (no tap decode, no bounds checks)
+// MODE 2: 1x1, stride 1, pad 0, OH*OW % 4 == 0 : the column matrix IS the input -> 16-byte loads
+template <int MODE>
+struct ConvGemmPolicy
+{
+    using Params = ConvGemmParams;
+
+    struct ALoad
+    {
+        const float* base;
+        __device__ ALoad(const Params& p, int, int m4) : base(p.Wt + m4) {}
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Kp); // Wt zero padded in both dims
+        }
+    };
+
+    struct BLoad
+    {
+        const float* ptr[MODE == 2 ? 1 : 4]; // &in[n][0][iy0][ix0] of each of the 4 columns (may point before the plane)
+        int iy0[MODE == 0 ? 4 : 1], ix0[MODE == 0 ? 4 : 1];
+        unsigned valid; // bit e: column n4+e < Ntot
+        __device__ BLoad(const Params& p, int, int n4)
+        {
+            valid = 0;
+            if (MODE == 2)
+            {
+                // 4 consecutive columns stay inside one image (OHW % 4 == 0, n4 % 4 == 0)
+                const int img = n4 / p.OHW, rem = n4 - img * p.OHW;
+                valid = n4 < p.Ntot ? 0xfu : 0u;
+                ptr[0] = p.in + ((size_t)img * p.C) * p.HW + rem;
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const int col = n4 + e;
+                    const bool ok = col < p.Ntot;
+                    const int cc = ok ? col : 0;
+                    const int img = cc / p.OHW, rem = cc - img * p.OHW;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    const int y0 = oy * p.SH - p.PT, x0 = ox * p.SW - p.PL;
+                    if (MODE == 0)
+                    {
+                        iy0[e] = y0;
+                        ix0[e] = x0;
+                    }
+                    ptr[e] = p.in + ((size_t)img * p.C) * p.HW + (ptrdiff_t)y0 * p.W + x0;
+                    valid |= ok ? (1u << e) : 0u;
+                }
+            }
+        }
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (krow < p.Kd)
+            {
+                if (MODE == 2)
+                {
+                    if (valid) return *reinterpret_cast<const float4*>(ptr[0] + (size_t)krow * p.HW);
+                }
+                else if (MODE == 1)
+                {
+                    const size_t koff = (size_t)krow * p.HW;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (valid & (1u << e)) v[e] = ptr[e][koff];
+                }
+                else
+                {
+                    const int c = krow / p.KHW, r = krow - c * p.KHW;
+                    const int u = r / p.KW, w = r - u * p.KW;
+                    const ptrdiff_t koff = (ptrdiff_t)c * p.HW + (ptrdiff_t)u * p.W + w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        const bool ok = (valid & (1u << e)) && ((unsigned)(iy0[e] + u) < (unsigned)p.H) &&
+                                        ((unsigned)(ix0[e] + w) < (unsigned)p.W);
+                        if (ok) v[e] = ptr[e][koff];
+                    }
+                }
+            }
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    struct Store
+    {
+        float* base;
+        bool ok;
+        __device__ Store(const Params& p, int, int n)
+        {
+            ok = n < p.Ntot;
+            const int cc = ok ? n : 0;
+            const int img = cc / p.OHW, rem = cc - img * p.OHW;
+            base = p.out + ((size_t)img * p.K) * p.OHW + rem;
+        }
+        __device__ void put(const Params& p, int m, float v) const
+        {
+            if (ok && m < p.K)
+            {
+                if (p.has_bias) v += p.bias[m];
+                if (p.relu) v = fmaxf(v, 0.f);
+                base[(size_t)m * p.OHW] = v;
+            }
+        }
+    };
+};
+
+using ConvShapeBig = GemmShape<128, 128, 16, 2, 2>;
+using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
+constexpr int kConvKTile = 16;
+constexpr int kConvColTile = 128;
+
+static bool conv_small_m(int K) { return K <= 64; }
+
+void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
+{
+    const int Kd = p.input_channels * p.kernel_h * p.kernel_w;
+    *kd_padded = round_up(Kd, kConvKTile);
+    *k_padded = round_up(p.output_channels, conv_small_m(p.output_channels) ? 64 : 128);
+}
+
+// K7: Wt[q][Kp] = W[k][q], zero padded (the GPU analogue of packed_sgemm_init, avx/sgemm.cpp:312-346).
+__global__ __launch_bounds__(256) void igemm_pack_weights_kernel(float* __restrict__ Wt, const float* __restrict__ w, int K,
+                                                                int Kd, int Kp)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (k < K) Wt[(size_t)q * Kp + k] = w[(size_t)k * Kd + q];
+}
+
+int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s)
+{
+    if (p.group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
+    int kdp, kp;
+    igemm_packed_dims(p, &kdp, &kp);
+    const int Kd = p.input_channels * p.kernel_h * p.kernel_w;
+    if (Kd > 65535) return fail(FHIP_E_BADARG, "C*kh*kw too large");
+    StageTimer tm(FHIP_STAGE_INIT, s);
+    FHIP_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)kdp * kp * sizeof(float), s));
+    hipLaunchKernelGGL(igemm_pack_weights_kernel, dim3(ceil_div(p.output_channels, 256), Kd), dim3(256), 0, s, packed, kernel,
+                       p.output_channels, Kd, kp);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+template <class Shape, int MODE>
+static void launch(const ConvGemmParams& g0, hipStream_t s)
+{
+    ConvGemmParams g = g0;
+    g.m_tiles = g.Kp / Shape::BM;
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
+                       g);
+}
+
+// force_no_act: the NAIVE algo ignores activation (avx/booster.cpp:41-61).
+int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
+                  bool force_no_act, hipStream_t s)
+{
+    if (p.group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
+    if (batch < 1) return fail(FHIP_E_BADARG, "batch < 1");
+    if (p.bias_term && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    ConvGemmParams g;
+    g.batches = 1;
+    g.Wt = packed;
+    g.in = in;
+    g.out = out;
+    g.bias = bias;
+    g.C = p.input_channels;
+    g.K = p.output_channels;
+    g.H = p.input_h;
+    g.W = p.input_w;
+    g.OH = p.output_h;
+    g.OW = p.output_w;
+    g.SH = p.stride_h > 0 ? p.stride_h : 1;
+    g.SW = p.stride_w > 0 ? p.stride_w : 1;
+    g.PL = p.pad_left;
+    g.PT = p.pad_top;
+    g.KH = p.kernel_h;
+    g.KW = p.kernel_w;
+    g.Kd = g.C * g.KH * g.KW;
+    int kdp;
+    igemm_packed_dims(p, &kdp, &g.Kp);
+    g.OHW = g.OH * g.OW;
+    g.HW = g.H * g.W;
+    g.KHW = g.KH * g.KW;
+    const long long ntot = (long long)batch * g.OHW;
+    if (ntot > 0x7fffff00LL) return fail(FHIP_E_BADARG, "N*Ho*Wo exceeds 32-bit column indices");
+    g.Ntot = (int)ntot;
+    g.has_bias = p.bias_term != 0;
+    g.relu = (p.activation == FHIP_ACT_RELU) && !force_no_act;
+    g.k_tiles = kdp / kConvKTile;
+    g.n_tiles = ceil_div(g.Ntot, kConvColTile);
+    g.m_tiles = 0;
+
+    const bool one = g.KH == 1 && g.KW == 1 && p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;
+    int mode = 0;
+    if (one) mode = (g.SH == 1 && g.SW == 1 && (g.OHW % 4) == 0) ? 2 : 1;
+    const bool small = conv_small_m(g.K);
+    StageTimer tm(FHIP_STAGE_IGEMM, s);
+    if (small)
+    {
+        if (mode == 2) launch<ConvShapeSmallM, 2>(g, s);
+        else if (mode == 1) launch<ConvShapeSmallM, 1>(g, s);
+        else launch<ConvShapeSmallM, 0>(g, s);
+    }
+    else
+    {
+        if (mode == 2) launch<ConvShapeBig, 2>(g, s);
+        else if (mode == 1) launch<ConvShapeBig, 1>(g, s);
+        else launch<ConvShapeBig, 0>(g, s);
+    }
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+} // namespace fhip

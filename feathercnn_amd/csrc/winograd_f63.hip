@@ -1,0 +1,382 @@
+// winograd_f63.hip -- Winograd F(6x6,3x3) for gfx950: filter / input / output transforms and the 64-way
+// batched tile GEMM.  Replaces the reference's non-fused AVX pipeline
+//   transformKernel_F6x6_3x3          src/booster/avx/winograd_kernels_F63.cpp:222-271
+//   pad_input + winogradInputFrameTransformSeq   avx/generic_kernels.cpp:31-48, winograd_kernels_F63.cpp:327-513
+//   TensorGEMM                        winograd_kernels_F63.cpp:518-692
+//   winogradOutputTransform<relu,bias> winograd_kernels_F63.cpp:1088-1269
+// with the same transform matrices (G :224-234, B^T :297-324, A^T :1039-1046) and the same edge rules
+// (zero-filled edge tiles :378-414, clipped stores :1200-1232), but none of its layouts:
+//
+//   U[xi][Cp][Kp]   filters, xi = 8*i + j frequency point, k (output channel) contiguous, zero padded
+//   V[xi][C][Pp]    transformed input, column p = n*T + ty*TX + tx (tile of image n) contiguous
+//   M[xi][K][Pp]    tile-GEMM output
+//
+// i.e. every xi is a plain k-major GEMM operand pair for gemm_core.h, every transform kernel maps one
+// tile to one lane with lanes running along p, so all 64 V stores / M loads of a wave are 256-byte
+// coalesced rows, and the padding (pad_input) is folded into the input transform's bounds checks
+// instead of a padded copy of the input.
+#include "gemm_core.h"
+
+namespace fhip
+{
+
+// ---------------------------------------------------------------------------------------------------
+// B^T d (8 -> 8) and A^T m (8 -> 6) butterflies (the NNPACK/ncnn F(6,3) variant the reference uses).
+__device__ __forceinline__ void bt8(float& r0, float& r1, float& r2, float& r3, float& r4, float& r5, float& r6, float& r7)
+{
+    const float o0 = (r0 - r6) + 5.25f * (r4 - r2);
+    const float o7 = (r7 - r1) + 5.25f * (r3 - r5);
+    const float t1 = (r2 + r6) - 4.25f * r4;
+    const float t2 = (r1 + r5) - 4.25f * r3;
+    const float p1 = r6 + (0.25f * r2 - 1.25f * r4);
+    const float p2 = (0.5f * r1 - 2.5f * r3) + 2.f * r5;
+    const float q1 = r6 + 4.f * (r2 - 1.25f * r4);
+    const float q2 = (2.f * r1 - 2.5f * r3) + 0.5f * r5;
+    r0 = o0;
+    r1 = t1 + t2;
+    r2 = t1 - t2;
+    r3 = p1 + p2;
+    r4 = p1 - p2;
+    r5 = q1 + q2;
+    r6 = q1 - q2;
+    r7 = o7;
+}
+
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float m6, float m7,
+                                    float& s0, float& s1, float& s2, float& s3, float& s4, float& s5)
+{
+    const float a12 = m1 + m2, d12 = m1 - m2;
+    const float a34 = m3 + m4, d34 = m3 - m4;
+    const float a56 = m5 + m6, d56 = m5 - m6;
+    s0 = (m0 + a12) + (a34 + 32.f * a56);
+    s1 = (d12 + 2.f * d34) + 16.f * d56;
+    s2 = (a12 + 4.f * a34) + 8.f * a56;
+    s3 = (d12 + 8.f * d34) + 4.f * d56;
+    s4 = (a12 + 16.f * a34) + 2.f * a56;
+    s5 = ((d12 + 32.f * d34) + d56) + m7;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: U = G g G^T, one (k, c) filter per lane, lanes along k so the 64 stores per lane are coalesced rows
+// of U[xi][c][.].  One-time work (ConvBooster::Init).
+__global__ __launch_bounds__(256) void wino_filter_transform_kernel(float* __restrict__ U, const float* __restrict__ w,
+                                                                   int C, int K, int Cp, int Kp)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= K) return;
+    const float* g = w + ((size_t)k * C + c) * 9;
+    float gg[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gg[i][j] = g[i * 3 + j];
+    const float G[8][3] = {{1.0f, 0.0f, 0.0f},
+                           {-2.0f / 9, -2.0f / 9, -2.0f / 9},
+                           {-2.0f / 9, 2.0f / 9, -2.0f / 9},
+                           {1.0f / 90, 1.0f / 45, 2.0f / 45},
+                           {1.0f / 90, -1.0f / 45, 2.0f / 45},
+                           {1.0f / 45, 1.0f / 90, 1.0f / 180},
+                           {1.0f / 45, -1.0f / 90, 1.0f / 180},
+                           {0.0f, 0.0f, 1.0f}};
+    float mid[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mid[i][j] = G[i][0] * gg[0][j] + G[i][1] * gg[1][j] + G[i][2] * gg[2][j];
+    const size_t xi_stride = (size_t)Cp * Kp;
+    float* up = U + (size_t)c * Kp + k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            up[(size_t)(i * 8 + j) * xi_stride] = mid[i][0] * G[j][0] + mid[i][1] * G[j][1] + mid[i][2] * G[j][2];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: V = B^T d B on 8x8 tiles at stride 6.  One tile per lane; padding and edge tiles are bounds checks.
+struct WinoXformParams
+{
+    int C, K, H, W, OH, OW, PL, PT;
+    int TX, T;   // tiles per row, tiles per image
+    int P, Pp;   // columns, padded columns
+    int N;
+};
+
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __restrict__ V, const float* __restrict__ in,
+                                                                  const WinoXformParams q)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (p >= q.P) return;
+    const int n = p / q.T, t = p - n * q.T;
+    const int ty = t / q.TX, tx = t - ty * q.TX;
+    const int y0 = ty * 6 - q.PT, x0 = tx * 6 - q.PL;
+    const float* ip = in + ((size_t)n * q.C + c) * q.H * q.W;
+
+    float d[8][8];
+    const bool interior = (y0 >= 0) && (x0 >= 0) && (y0 + 8 <= q.H) && (x0 + 8 <= q.W);
+    if (interior)
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[i][j] = ip[(size_t)(y0 + i) * q.W + x0 + j];
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const int y = y0 + i;
+            const bool yok = (unsigned)y < (unsigned)q.H;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const int x = x0 + j;
+                const bool ok = yok && ((unsigned)x < (unsigned)q.W);
+                d[i][j] = ok ? ip[(size_t)y * q.W + x] : 0.f;
+            }
+        }
+    }
+    // B^T d : along the row index, for every column
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bt8(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
+    // (.) B : along the column index, for every row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
+
+    const size_t xi_stride = (size_t)q.C * q.Pp;
+    float* vp = V + (size_t)c * q.Pp + p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * xi_stride] = d[i][j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: Y = A^T m A, + bias, ReLU, clipped 6x6 store.
+template <bool HAS_BIAS, bool RELU>
+__global__ __launch_bounds__(256) void wino_output_transform_kernel(float* __restrict__ out, const float* __restrict__ M,
+                                                                   const float* __restrict__ bias, const WinoXformParams q)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (p >= q.P) return;
+    const int n = p / q.T, t = p - n * q.T;
+    const int ty = t / q.TX, tx = t - ty * q.TX;
+
+    const size_t xi_stride = (size_t)q.K * q.Pp;
+    const float* mp = M + (size_t)k * q.Pp + p;
+    float m[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[i][j] = mp[(size_t)(i * 8 + j) * xi_stride];
+
+    float tmp[6][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        at6(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], m[6][j], m[7][j], tmp[0][j], tmp[1][j], tmp[2][j],
+            tmp[3][j], tmp[4][j], tmp[5][j]);
+    const float b = HAS_BIAS ? bias[k] : 0.f;
+    const int oy0 = ty * 6, ox0 = tx * 6;
+    float* op = out + (((size_t)n * q.K + k) * q.OH + oy0) * q.OW + ox0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+    {
+        float y[6];
+        at6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], tmp[a][6], tmp[a][7], y[0], y[1], y[2], y[3],
+            y[4], y[5]);
+        if (oy0 + a < q.OH)
+        {
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb)
+                if (ox0 + bb < q.OW)
+                {
+                    float v = y[bb] + b;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    op[(size_t)a * q.OW + bb] = v;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: tile GEMM policy for gemm_core.h
+struct WinoGemmPolicy
+{
+    struct Params
+    {
+        int batches, m_tiles, n_tiles, k_tiles;
+        const float* U;
+        const float* V;
+        float* M;
+        int C, K, Cp, Kp, Pp;
+    };
+    struct ALoad
+    {
+        const float* base;
+        __device__ ALoad(const Params& p, int xi, int m4) : base(p.U + (size_t)xi * p.Cp * p.Kp + m4) {}
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Kp); // U is zero padded to [Cp][Kp]
+        }
+    };
+    struct BLoad
+    {
+        const float* base;
+        __device__ BLoad(const Params& p, int xi, int n4) : base(p.V + (size_t)xi * p.C * p.Pp + n4) {}
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            if (krow < p.C) return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Pp);
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    struct Store
+    {
+        float* base;
+        __device__ Store(const Params& p, int xi, int n) : base(p.M + (size_t)xi * p.K * p.Pp + n) {}
+        __device__ void put(const Params& p, int m, float v) const
+        {
+            if (m < p.K) base[(size_t)m * p.Pp] = v;
+        }
+    };
+};
+
+using WinoShapeBig = GemmShape<128, 128, 16, 2, 2>;
+using WinoShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
+constexpr int kWinoColTile = 128; // column padding of V / M
+constexpr int kWinoKTile = 16;    // reduction padding of U
+
+static bool wino_small_m(int K) { return K <= 64; }
+
+int winograd_plan(const fhip_conv_param& p, int batch, fhip_winograd_plan* plan)
+{
+    if (p.kernel_h != 3 || p.kernel_w != 3 || p.stride_h > 1 || p.stride_w > 1 || p.group > 1)
+        return fail(FHIP_E_UNSUPPORTED, "Winograd F(6x6,3x3) needs a 3x3 stride-1 group-1 convolution");
+    if (batch < 1) return fail(FHIP_E_BADARG, "batch < 1");
+    const int hp = p.input_h + p.pad_top + p.pad_bottom, wp = p.input_w + p.pad_left + p.pad_right;
+    if (hp < 3 || wp < 3) return fail(FHIP_E_BADARG, "input smaller than the kernel");
+    // nRowBlocks / nColBlocks exactly as WINOGRADF63_Forward (avx/booster.cpp:209-211)
+    plan->tiles_x = (wp + 3) / 6;
+    plan->tiles_y = (hp + 3) / 6;
+    plan->tiles_per_image = plan->tiles_x * plan->tiles_y;
+    const long long P = (long long)plan->tiles_per_image * batch;
+    if (P > 0x7fffff00LL) return fail(FHIP_E_BADARG, "too many Winograd tiles for 32-bit column indices");
+    plan->columns = (int)P;
+    plan->columns_padded = round_up((int)P, kWinoColTile);
+    plan->in_channels_padded = round_up(p.input_channels, kWinoKTile);
+    plan->out_channels_padded = round_up(p.output_channels, wino_small_m(p.output_channels) ? 64 : 128);
+    plan->v_offset_bytes = 0;
+    plan->v_bytes = round_up_sz((size_t)64 * p.input_channels * plan->columns_padded * sizeof(float), 256);
+    plan->m_offset_bytes = plan->v_bytes;
+    plan->m_bytes = round_up_sz((size_t)64 * p.output_channels * plan->columns_padded * sizeof(float), 256);
+    plan->u_bytes = (size_t)64 * plan->in_channels_padded * plan->out_channels_padded * sizeof(float);
+    return FHIP_OK;
+}
+
+static WinoXformParams xform_params(const fhip_conv_param& p, int batch, const fhip_winograd_plan& pl)
+{
+    WinoXformParams q;
+    q.C = p.input_channels;
+    q.K = p.output_channels;
+    q.H = p.input_h;
+    q.W = p.input_w;
+    q.OH = p.output_h;
+    q.OW = p.output_w;
+    q.PL = p.pad_left;
+    q.PT = p.pad_top;
+    q.TX = pl.tiles_x;
+    q.T = pl.tiles_per_image;
+    q.P = pl.columns;
+    q.Pp = pl.columns_padded;
+    q.N = batch;
+    return q;
+}
+
+int winograd_transform_kernel(const fhip_conv_param& p, float* u, const float* kernel, hipStream_t s)
+{
+    fhip_winograd_plan pl;
+    int rc = winograd_plan(p, 1, &pl);
+    if (rc) return rc;
+    StageTimer tm(FHIP_STAGE_INIT, s);
+    FHIP_CHECK_HIP(hipMemsetAsync(u, 0, pl.u_bytes, s));
+    dim3 grid(ceil_div(p.output_channels, 256), p.input_channels);
+    hipLaunchKernelGGL(wino_filter_transform_kernel, grid, dim3(256), 0, s, u, kernel, p.input_channels, p.output_channels,
+                       pl.in_channels_padded, pl.out_channels_padded);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, const float* input, hipStream_t s)
+{
+    fhip_winograd_plan pl;
+    int rc = winograd_plan(p, batch, &pl);
+    if (rc) return rc;
+    const WinoXformParams q = xform_params(p, batch, pl);
+    StageTimer tm(FHIP_STAGE_WINO_INPUT, s);
+    dim3 grid(ceil_div(q.P, 256), q.C);
+    hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const float* u, const float* v, hipStream_t s)
+{
+    fhip_winograd_plan pl;
+    int rc = winograd_plan(p, batch, &pl);
+    if (rc) return rc;
+    WinoGemmPolicy::Params g;
+    g.batches = 64;
+    g.U = u;
+    g.V = v;
+    g.M = m;
+    g.C = p.input_channels;
+    g.K = p.output_channels;
+    g.Cp = pl.in_channels_padded;
+    g.Kp = pl.out_channels_padded;
+    g.Pp = pl.columns_padded;
+    g.k_tiles = g.Cp / kWinoKTile;
+    g.n_tiles = g.Pp / kWinoColTile;
+    StageTimer tm(FHIP_STAGE_WINO_GEMM, s);
+    if (wino_small_m(g.K))
+    {
+        g.m_tiles = g.Kp / WinoShapeSmallM::BM;
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                           dim3(WinoShapeSmallM::THREADS), 0, s, g);
+    }
+    else
+    {
+        g.m_tiles = g.Kp / WinoShapeBig::BM;
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                           dim3(WinoShapeBig::THREADS), 0, s, g);
+    }
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
+                              hipStream_t s)
+{
+    fhip_winograd_plan pl;
+    int rc = winograd_plan(p, batch, &pl);
+    if (rc) return rc;
+    const WinoXformParams q = xform_params(p, batch, pl);
+    const bool has_bias = p.bias_term != 0, relu = p.activation == FHIP_ACT_RELU;
+    if (has_bias && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    StageTimer tm(FHIP_STAGE_WINO_OUTPUT, s);
+    dim3 grid(ceil_div(q.P, 256), q.K);
+    if (has_bias && relu)
+        hipLaunchKernelGGL((wino_output_transform_kernel<true, true>), grid, dim3(256), 0, s, output, m, bias, q);
+    else if (has_bias)
+        hipLaunchKernelGGL((wino_output_transform_kernel<true, false>), grid, dim3(256), 0, s, output, m, bias, q);
+    else if (relu)
+        hipLaunchKernelGGL((wino_output_transform_kernel<false, true>), grid, dim3(256), 0, s, output, m, bias, q);
+    else
+        hipLaunchKernelGGL((wino_output_transform_kernel<false, false>), grid, dim3(256), 0, s, output, m, bias, q);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+} // namespace fhip

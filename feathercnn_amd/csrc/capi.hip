@@ -38,6 +38,20 @@ int fail_hip(hipError_t e, const char* what)
     return FHIP_E_HIP;
 }
 
+int device_compute_units()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0)
+    {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        cached[dev] = cu;
+    }
+    return cached[dev];
+}
+
 // ---- stage timing -----------------------------------------------------------------------------------
 struct TimedLaunch
 {

@@ -35,6 +35,9 @@ struct StageTimer
     int slot;
 };
 
+// Compute units of the current device (cached per device; 256 on MI355X).
+int device_compute_units();
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 inline size_t round_up_sz(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -11,12 +11,28 @@
 //     (A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31]).
 //   * Both operand tiles live in LDS k-major ([BK][BM] / [BK][BN], the m / n index contiguous), so an
 //     operand fetch is one conflict-free ds_read_b32 per lane (two 32-lane halves read two k rows) and a
-//     global->LDS copy is a straight 16-byte-per-lane row copy.  fp32 MFMA is 1/16 the bf16 rate, so
-//     LDS bandwidth is nowhere near the limit (16 B/clk/CU used of 128); what matters is keeping the
-//     matrix pipe issued back to back: 2x2 independent 32x32 accumulators per wave, register-prefetched
-//     global loads one k-tile ahead, LDS double buffer with ONE barrier per k-tile, >= 2 blocks per CU.
-//   * 1-D grid, XCD-aware remap: consecutive virtual block ids run on one XCD and walk m-tiles fastest,
-//     so the blocks that share a B panel / an A panel hit the same private L2.
+//     global->LDS copy is a straight 16-byte-per-lane row copy.  fp32 MFMA is 1/16 the bf16 rate, so LDS
+//     bandwidth is nowhere near the limit (16 B/clk/CU used of 128); what decides the rate is whether the
+//     matrix pipe is issued back to back.  Measured on MI355X (tools/gemm_bench.hip, tools/loop_probe.hip):
+//     this loop structure (LDS operands + one barrier and one LDS write pass per k-tile) sustains ~91 % of
+//     the 157 TF peak with >= 2 waves per SIMD; what takes it away is whatever stalls a wave in front of its
+//     MFMAs.  The rules this kernel follows, each from a measurement:
+//       - one output tile per block, 4 blocks per CU, hardware block scheduling.  A persistent variant with
+//         a static or an atomic tile scheduler was built and measured SLOWER (52-66 % vs 58-70 %): with ~12
+//         tiles per CU the static split loses 17 % to unlucky CUs, a contended atomic costs microseconds per
+//         tile, and lock-stepped blocks collide in the CU's single VMEM address pipe;
+//       - global loads are issued TWO k-tiles ahead (registers); the LDS write of k-tile t+1 happens at the top
+//         of iteration t, a full k-tile after its loads were issued, so its vmcnt wait is free; one barrier
+//         per k-tile;
+//       - every global load is UNCONDITIONAL (clamped address + validity mask applied at LDS-write time): a
+//         load under a branch makes hipcc wait vmcnt(0) right behind it (the merge with the zero needs the
+//         value), which serialises the pipeline on the global round trip (measured 66 % -> 50 %);
+//       - accumulators leave through a per-wave LDS transpose (in the operand buffers, free by then) as 16-byte
+//         row stores: a VMEM instruction costs the CU's address pipe ~16 clk whatever its width, so 64 dword
+//         stores per lane were 4096 clk of a C=64 tile's 8192 MFMA clk; 16 dwordx4 stores are 1024.
+//   * XCD-aware: block b runs on XCD b % 8 (observed; speed only, never correctness).  The 1-D grid is remapped
+//     so consecutive virtual ids land on one XCD and walk m-tiles fastest: blocks that share a B panel / an A
+//     panel hit the same private 4 MiB L2 at the same time.
 #pragma once
 
 #include "common.h"
@@ -24,18 +40,23 @@
 namespace fhip
 {
 
-template <int BM_, int BN_, int BK_, int WAVES_M_, int WAVES_N_>
+template <int BM_, int BN_, int BK_, int WAVES_M_, int WAVES_N_, int BLOCKS_PER_CU_ = 4>
 struct GemmShape
 {
     static constexpr int BM = BM_, BN = BN_, BK = BK_;
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
-    static constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int WAVES = WAVES_M * WAVES_N;
+    static constexpr int BLOCKS_PER_CU = BLOCKS_PER_CU_;
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N; // per-wave output tile
     static constexpr int TM = WTM / 32, TN = WTN / 32;           // 32x32 MFMA tiles per wave
     static constexpr int A_F4_PER_ROW = BM / 4, B_F4_PER_ROW = BN / 4;
     static constexpr int A_ROWS_PER_PASS = THREADS / A_F4_PER_ROW, B_ROWS_PER_PASS = THREADS / B_F4_PER_ROW;
     static constexpr int A_PASSES = BK / A_ROWS_PER_PASS, B_PASSES = BK / B_ROWS_PER_PASS;
-    static constexpr int LDS_FLOATS = 2 * BK * (BM + BN);
+    static constexpr int OPERAND_FLOATS = 2 * BK * (BM + BN); // double-buffered A and B tiles
+    static constexpr int EPI_LD = 36;                         // row pitch of the 32x32 transpose scratch (16-B aligned rows)
+    static constexpr int EPI_FLOATS = WAVES * 32 * EPI_LD;    // one scratch per wave, overlaid on the operand buffers
+    static constexpr int LDS_FLOATS = OPERAND_FLOATS > EPI_FLOATS ? OPERAND_FLOATS : EPI_FLOATS;
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
     static_assert(THREADS % A_F4_PER_ROW == 0 && THREADS % B_F4_PER_ROW == 0, "loader mapping");
     static_assert(A_PASSES >= 1 && B_PASSES >= 1 && BK % A_ROWS_PER_PASS == 0 && BK % B_ROWS_PER_PASS == 0, "BK too small");
@@ -45,18 +66,23 @@ struct GemmShape
 // Policy concept:
 //   struct Params { int batches, m_tiles, n_tiles, k_tiles; ... };
 //   struct ALoad { ALoad(const Params&, int batch, int m4); float4 load(const Params&, int krow) const; };
-//   struct BLoad { BLoad(const Params&, int batch, int n4); float4 load(const Params&, int krow) const; };
-//       (m4 / n4 = first of the 4 consecutive rows / columns this thread always fetches)
-//   struct Store { Store(const Params&, int batch, int n); void put(const Params&, int m, float v) const; };
-template <class Shape, class Policy>
-__global__ __launch_bounds__(Shape::THREADS, 2) void gemm_mfma_kernel(const typename Policy::Params prm)
+//   struct BLoad { BLoad(const Params&, int batch, int n4); float4 load(const Params&, int krow, unsigned& ok) const; };
+//       (m4 / n4 = first of the 4 consecutive rows / columns this thread always fetches; loads are unconditional
+//        from clamped addresses, `ok` bit e = element e is real data, zero-fill happens at LDS-write time)
+//   struct Store { Store(const Params&, int batch, int n4); void put4(const Params&, int m, float4 v) const; };
+//       (4 consecutive output columns n4..n4+3 of row m)
+//
+// ABLATE (measurement builds only, tools/gemm_bench.hip; the product always uses 0):
+//   bit 0: no global fetch after the prologue (MFMA + LDS only; results are garbage), bit 1: no accumulator store.
+template <class Shape, class Policy, int ABLATE = 0>
+__global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREADS / 256) void gemm_mfma_kernel(
+    const typename Policy::Params prm)
 {
     constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK;
+    // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits)
     __shared__ __attribute__((aligned(16))) float lds[Shape::LDS_FLOATS];
-    // As[buf] = lds + buf * BK*BM ; Bs[buf] = lds + 2*BK*BM + buf * BK*BN  (plain arithmetic: a runtime-indexed
-    // pointer array would be demoted to scratch)
-    float* const As0 = lds;
-    float* const Bs0 = lds + 2 * BK * BM;
+    float* const As0 = lds;               // As[buf] = As0 + buf * BK*BM
+    float* const Bs0 = lds + 2 * BK * BM; // Bs[buf] = Bs0 + buf * BK*BN
 
     const int nwg = prm.batches * prm.m_tiles * prm.n_tiles;
     int vid = xcd_remap(blockIdx.x, nwg);
@@ -65,6 +91,7 @@ __global__ __launch_bounds__(Shape::THREADS, 2) void gemm_mfma_kernel(const type
     const int nt = vid % prm.n_tiles;
     const int batch = vid / prm.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    const int k_tiles = prm.k_tiles;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -78,11 +105,12 @@ __global__ __launch_bounds__(Shape::THREADS, 2) void gemm_mfma_kernel(const type
     const typename Policy::BLoad bload(prm, batch, n0 + b_c4 * 4);
 
     float4 pa[Shape::A_PASSES], pb[Shape::B_PASSES];
+    unsigned pok[Shape::B_PASSES];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < Shape::A_PASSES; ++i) pa[i] = aload.load(prm, kt * BK + a_r + i * Shape::A_ROWS_PER_PASS);
 #pragma unroll
-        for (int i = 0; i < Shape::B_PASSES; ++i) pb[i] = bload.load(prm, kt * BK + b_r + i * Shape::B_ROWS_PER_PASS);
+        for (int i = 0; i < Shape::B_PASSES; ++i) pb[i] = bload.load(prm, kt * BK + b_r + i * Shape::B_ROWS_PER_PASS, pok[i]);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -90,7 +118,14 @@ __global__ __launch_bounds__(Shape::THREADS, 2) void gemm_mfma_kernel(const type
             *reinterpret_cast<float4*>(&As0[buf * (BK * BM) + (a_r + i * Shape::A_ROWS_PER_PASS) * BM + a_c4 * 4]) = pa[i];
 #pragma unroll
         for (int i = 0; i < Shape::B_PASSES; ++i)
-            *reinterpret_cast<float4*>(&Bs0[buf * (BK * BN) + (b_r + i * Shape::B_ROWS_PER_PASS) * BN + b_c4 * 4]) = pb[i];
+        {
+            float4 v = pb[i];
+            v.x = (pok[i] & 1u) ? v.x : 0.f;
+            v.y = (pok[i] & 2u) ? v.y : 0.f;
+            v.z = (pok[i] & 4u) ? v.z : 0.f;
+            v.w = (pok[i] & 8u) ? v.w : 0.f;
+            *reinterpret_cast<float4*>(&Bs0[buf * (BK * BN) + (b_r + i * Shape::B_ROWS_PER_PASS) * BN + b_c4 * 4]) = v;
+        }
     };
 
     f32x16 acc[Shape::TM][Shape::TN];
@@ -101,50 +136,72 @@ __global__ __launch_bounds__(Shape::THREADS, 2) void gemm_mfma_kernel(const type
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- prologue: k-tile 0 -> LDS buffer 0, k-tile 1 -> registers
     fetch(0);
     stash(0);
+    if (k_tiles > 1) fetch(1);
     __syncthreads();
 
     const int a_off = half * BM + wm * Shape::WTM + l31;
     const int b_off = half * BN + wn * Shape::WTN + l31;
     int cur = 0;
-    for (int kt = 0; kt < prm.k_tiles; ++kt)
+    for (int kt = 0; kt < k_tiles; ++kt)
     {
-        const bool more = kt + 1 < prm.k_tiles;
-        if (more) fetch(kt + 1); // global loads for the next k-tile fly under this tile's MFMAs
+        // k-tile kt+1 (in registers since the previous iteration) -> the other LDS buffer; k-tile kt+2 -> registers
+        if (kt + 1 < k_tiles) stash(cur ^ 1);
+        if (kt + 2 < k_tiles && !(ABLATE & 1)) fetch(kt + 2);
+
         const float* as = As0 + cur * (BK * BM) + a_off;
         const float* bs = Bs0 + cur * (BK * BN) + b_off;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2)
+        for (int kp = 0; kp < BK / 2; ++kp)
         {
-            float a[Shape::TM], b[Shape::TN];
+            float fa[Shape::TM], fbv[Shape::TN];
 #pragma unroll
-            for (int i = 0; i < Shape::TM; ++i) a[i] = as[kk * BM + i * 32];
+            for (int i = 0; i < Shape::TM; ++i) fa[i] = as[(2 * kp) * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < Shape::TN; ++j) b[j] = bs[kk * BN + j * 32];
+            for (int j = 0; j < Shape::TN; ++j) fbv[j] = bs[(2 * kp) * BN + j * 32];
 #pragma unroll
             for (int i = 0; i < Shape::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Shape::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fbv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // ---- epilogue.  After the last barrier nobody reads the operand buffers any more: each wave transposes its
+    // 32x32 MFMA tiles through a private piece of them (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2)
+    // + 4 * (lane >> 5)) and stores 4 consecutive columns per lane.  Wave-private + in-order LDS queue: no barrier.
+    if (ABLATE & 2)
+    {
+#pragma unroll
+        for (int i = 0; i < Shape::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Shape::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+    float* const scr = lds + wave * (32 * Shape::EPI_LD);
+    const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
 #pragma unroll
     for (int j = 0; j < Shape::TN; ++j)
     {
-        const int n = n0 + wn * Shape::WTN + j * 32 + l31;
-        const typename Policy::Store st(prm, batch, n);
+        const typename Policy::Store st(prm, batch, n0 + wn * Shape::WTN + j * 32 + e_c4);
 #pragma unroll
         for (int i = 0; i < Shape::TM; ++i)
         {
-            const int mbase = m0 + wm * Shape::WTM + i * 32 + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st.put(prm, mbase + (r & 3) + 8 * (r >> 2), acc[i][j][r]);
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * Shape::EPI_LD + l31] = acc[i][j][r];
+            const int mbase = m0 + wm * Shape::WTM + i * 32 + e_row;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+            {
+                const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * Shape::EPI_LD + e_c4]);
+                st.put4(prm, mbase + q * 8, v);
+            }
         }
     }
 }

@@ -82,34 +82,37 @@ struct ConvGemmPolicy
                 }
             }
         }
-        __device__ float4 load(const Params& p, int krow) const
+        // Unconditional loads from clamped addresses; `ok` says which of the 4 values are real (see gemm_core.h).
+        __device__ float4 load(const Params& p, int krow, unsigned& ok) const
         {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (krow < p.Kd)
+            const bool kin = krow < p.Kd;
+            const int kr = min(krow, p.Kd - 1);
+            if (MODE == 2)
             {
-                if (MODE == 2)
-                {
-                    if (valid) return *reinterpret_cast<const float4*>(ptr[0] + (size_t)krow * p.HW);
-                }
-                else if (MODE == 1)
-                {
-                    const size_t koff = (size_t)krow * p.HW;
+                ok = kin ? valid : 0u;
+                return *reinterpret_cast<const float4*>((valid ? ptr[0] : p.in) + (size_t)kr * p.HW);
+            }
+            float v[4];
+            if (MODE == 1)
+            {
+                ok = kin ? valid : 0u;
+                const size_t koff = (size_t)kr * p.HW;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (valid & (1u << e)) v[e] = ptr[e][koff];
-                }
-                else
-                {
-                    const int c = krow / p.KHW, r = krow - c * p.KHW;
-                    const int u = r / p.KW, w = r - u * p.KW;
-                    const ptrdiff_t koff = (ptrdiff_t)c * p.HW + (ptrdiff_t)u * p.W + w;
+                for (int e = 0; e < 4; ++e) v[e] = ptr[e][koff]; // ptr[e] of an invalid column points at column 0
+            }
+            else
+            {
+                const int c = kr / p.KHW, r = kr - c * p.KHW;
+                const int u = r / p.KW, w = r - u * p.KW;
+                const ptrdiff_t koff = (ptrdiff_t)c * p.HW + (ptrdiff_t)u * p.W + w;
+                ok = 0u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                    {
-                        const bool ok = (valid & (1u << e)) && ((unsigned)(iy0[e] + u) < (unsigned)p.H) &&
-                                        ((unsigned)(ix0[e] + w) < (unsigned)p.W);
-                        if (ok) v[e] = ptr[e][koff];
-                    }
+                for (int e = 0; e < 4; ++e)
+                {
+                    const bool in = kin && (valid & (1u << e)) && ((unsigned)(iy0[e] + u) < (unsigned)p.H) &&
+                                    ((unsigned)(ix0[e] + w) < (unsigned)p.W);
+                    ok |= in ? (1u << e) : 0u;
+                    v[e] = *(in ? ptr[e] + koff : p.in); // a padding tap reads in[0] and is zeroed at LDS-write time
                 }
             }
             return make_float4(v[0], v[1], v[2], v[3]);
@@ -118,28 +121,57 @@ struct ConvGemmPolicy
 
     struct Store
     {
-        float* base;
-        bool ok;
-        __device__ Store(const Params& p, int, int n)
+        float* ptr[4]; // &out[img][0][rem] of each of the 4 columns
+        unsigned valid;
+        bool wide; // the 4 columns are one aligned 16-byte piece of one image
+        __device__ Store(const Params& p, int, int n4)
         {
-            ok = n < p.Ntot;
-            const int cc = ok ? n : 0;
-            const int img = cc / p.OHW, rem = cc - img * p.OHW;
-            base = p.out + ((size_t)img * p.K) * p.OHW + rem;
-        }
-        __device__ void put(const Params& p, int m, float v) const
-        {
-            if (ok && m < p.K)
+            valid = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
             {
-                if (p.has_bias) v += p.bias[m];
-                if (p.relu) v = fmaxf(v, 0.f);
-                base[(size_t)m * p.OHW] = v;
+                const int col = n4 + e;
+                const bool ok = col < p.Ntot;
+                const int cc = ok ? col : 0;
+                const int img = cc / p.OHW, rem = cc - img * p.OHW;
+                ptr[e] = p.out + ((size_t)img * p.K) * p.OHW + rem;
+                valid |= ok ? (1u << e) : 0u;
+            }
+            wide = (valid == 0xfu) && ((p.OHW & 3) == 0) && (ptr[3] == ptr[0] + 3);
+        }
+        __device__ void put4(const Params& p, int m, float4 v) const
+        {
+            if (m >= p.K) return;
+            if (p.has_bias)
+            {
+                const float b = p.bias[m];
+                v.x += b;
+                v.y += b;
+                v.z += b;
+                v.w += b;
+            }
+            if (p.relu)
+            {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+            }
+            const size_t moff = (size_t)m * p.OHW;
+            if (wide)
+                *reinterpret_cast<float4*>(ptr[0] + moff) = v;
+            else
+            {
+                if (valid & 1u) ptr[0][moff] = v.x;
+                if (valid & 2u) ptr[1][moff] = v.y;
+                if (valid & 4u) ptr[2][moff] = v.z;
+                if (valid & 8u) ptr[3][moff] = v.w;
             }
         }
     };
 };
 
-using ConvShapeBig = GemmShape<128, 128, 16, 2, 2>;
+using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
 constexpr int kConvKTile = 16;
 constexpr int kConvColTile = 128;
@@ -182,8 +214,8 @@ static void launch(const ConvGemmParams& g0, hipStream_t s)
 {
     ConvGemmParams g = g0;
     g.m_tiles = g.Kp / Shape::BM;
-    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
-                       g);
+    g.n_tiles = ceil_div(g.Ntot, Shape::BN);
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s, g);
 }
 
 // force_no_act: the NAIVE algo ignores activation (avx/booster.cpp:41-61).
@@ -223,7 +255,6 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.has_bias = p.bias_term != 0;
     g.relu = (p.activation == FHIP_ACT_RELU) && !force_no_act;
     g.k_tiles = kdp / kConvKTile;
-    g.n_tiles = ceil_div(g.Ntot, kConvColTile);
     g.m_tiles = 0;
 
     const bool one = g.KH == 1 && g.KW == 1 && p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;

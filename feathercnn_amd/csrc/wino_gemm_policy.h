@@ -1,0 +1,53 @@
+// wino_gemm_policy.h -- operand loaders / accumulator store of the Winograd tile GEMM
+//   M_xi[K x P] = U_xi[K x C] * V_xi[C x P], xi = 0..63   (reference TensorGEMM,
+//   src/booster/avx/winograd_kernels_F63.cpp:518-692) for the shared main loop in gemm_core.h.
+#pragma once
+
+#include "gemm_core.h"
+
+namespace fhip
+{
+
+struct WinoGemmPolicy
+{
+    struct Params
+    {
+        int batches, m_tiles, n_tiles, k_tiles;
+        const float* U;
+        const float* V;
+        float* M;
+        int C, K, Cp, Kp, Pp;
+    };
+    struct ALoad
+    {
+        const float* base;
+        __device__ ALoad(const Params& p, int xi, int m4) : base(p.U + (size_t)xi * p.Cp * p.Kp + m4) {}
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Kp); // U is zero padded to [Cp][Kp]
+        }
+    };
+    struct BLoad
+    {
+        const float* base;
+        __device__ BLoad(const Params& p, int xi, int n4) : base(p.V + (size_t)xi * p.C * p.Pp + n4) {}
+        __device__ float4 load(const Params& p, int krow, unsigned& ok) const
+        {
+            // unconditional: rows past C re-read row C-1 and are zeroed at LDS-write time
+            ok = krow < p.C ? 0xfu : 0u;
+            return *reinterpret_cast<const float4*>(base + (size_t)min(krow, p.C - 1) * p.Pp);
+        }
+    };
+    struct Store
+    {
+        float* base;
+        __device__ Store(const Params& p, int xi, int n4) : base(p.M + (size_t)xi * p.K * p.Pp + n4) {}
+        __device__ void put4(const Params& p, int m, float4 v) const
+        {
+            if (m < p.K) *reinterpret_cast<float4*>(base + (size_t)m * p.Pp) = v; // Pp is a multiple of the column tile
+        }
+    };
+};
+
+
+} // namespace fhip

@@ -1,0 +1,121 @@
+// tools/gemm_bench.hip -- measurement harness for the shared MFMA main loop (gemm_core.h) on Winograd tile-GEMM
+// shapes: times variants of tile shape / occupancy / ablations with HIP events. Not part of the product.
+//   usage: gemm_bench [reps]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gemm_core.h"
+#include "wino_gemm_policy.h"
+#include "gemm_core_v0.h"
+
+using namespace fhip;
+namespace fhip
+{
+int fail(int c, const char*) { return c; }
+int fail_hip(hipError_t, const char*) { return -3; }
+StageTimer::StageTimer(int, hipStream_t) {}
+StageTimer::~StageTimer() {}
+} // namespace fhip
+
+#define CK(x)                                                                  \
+    do                                                                         \
+    {                                                                          \
+        hipError_t e = (x);                                                    \
+        if (e != hipSuccess)                                                   \
+        {                                                                      \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+struct Case
+{
+    int C, K, P;
+};
+
+static int g_cus = 256;
+static long long* g_prof = nullptr;
+
+template <class Shape, int ABLATE, bool V0 = false>
+double run(const char* name, const Case& cs, float* U, float* V, float* M, int reps)
+{
+    WinoGemmPolicy::Params g;
+    g.batches = 64;
+    g.U = U;
+    g.V = V;
+    g.M = M;
+    g.C = cs.C;
+    g.K = cs.K;
+    g.Cp = round_up(cs.C, Shape::BK);
+    g.Kp = round_up(cs.K, Shape::BM);
+    g.Pp = round_up(cs.P, Shape::BN);
+    g.k_tiles = g.Cp / Shape::BK;
+    g.n_tiles = g.Pp / Shape::BN;
+    g.m_tiles = g.Kp / Shape::BM;
+    const int tiles = g.batches * g.m_tiles * g.n_tiles;
+    dim3 grid(tiles);
+    auto launch = [&]() {
+        if constexpr (V0)
+            hipLaunchKernelGGL((gemm_mfma_kernel_v0<Shape, WinoGemmPolicy, ABLATE, 2>), grid, dim3(Shape::THREADS), 0, 0, g);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
+    };
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    const double tf = 2.0 * 64 * cs.K * cs.C * (double)cs.P / ms / 1e9;
+    printf("  %-34s C%4d K%4d P%6d grid %6d  %8.4f ms  %7.2f TF (%.1f%% of 157.3)\n", name, cs.C, cs.K, cs.P, grid.x, ms, tf, tf / 157.3 * 100);
+    return tf;
+}
+
+int main(int argc, char** argv)
+{
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    const Case cases[] = {{256, 256, 3200}, {512, 512, 800}, {512, 512, 288}, {128, 128, 11552}, {64, 64, 46208}, {64, 128, 11552}};
+    size_t maxU = 0, maxV = 0, maxM = 0;
+    for (auto& c : cases)
+    {
+        maxU = std::max(maxU, (size_t)64 * round_up(c.C, 32) * round_up(c.K, 256));
+        maxV = std::max(maxV, (size_t)64 * c.C * round_up(c.P, 256));
+        maxM = std::max(maxM, (size_t)64 * c.K * round_up(c.P, 256));
+    }
+    float *U, *V, *M;
+    CK(hipMalloc(&U, maxU * 4));
+    CK(hipMalloc(&V, maxV * 4));
+    CK(hipMalloc(&M, maxM * 4));
+    std::vector<float> h(1 << 20);
+    srand(1);
+    for (auto& x : h) x = (rand() / (float)RAND_MAX) * 2 - 1;
+    for (size_t off = 0; off < maxU; off += h.size()) CK(hipMemcpy(U + off, h.data(), std::min(h.size(), maxU - off) * 4, hipMemcpyHostToDevice));
+    for (size_t off = 0; off < maxV; off += h.size()) CK(hipMemcpy(V + off, h.data(), std::min(h.size(), maxV - off) * 4, hipMemcpyHostToDevice));
+    hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, 0);
+    printf("CUs %d\n", g_cus);
+    for (auto& c : cases)
+    {
+        printf("case C=%d K=%d P=%d\n", c.C, c.K, c.P);
+        for (int round = 0; round < 3; ++round)
+        {
+            run<GemmShapeV0<128, 128, 16, 2, 2>, 0, true>("v0 128x128x16", c, U, V, M, reps);
+            run<GemmShape<128, 128, 16, 2, 2, 4>, 0>("v1 128x128x16 bpc4", c, U, V, M, reps);
+            run<GemmShape<128, 128, 8, 2, 2, 4>, 0>("v1 128x128x8 bpc4", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("v1 128x64x16 bpc4", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 6>, 0>("v1 128x64x16 bpc6", c, U, V, M, reps);
+            run<GemmShape<128, 64, 32, 2, 2, 3>, 0>("v1 128x64x32 bpc3", c, U, V, M, reps);
+            run<GemmShape<64, 128, 16, 1, 4, 4>, 0>("v1 64x128x16 1x4 bpc4", c, U, V, M, reps);
+            run<GemmShape<64, 128, 16, 1, 4, 6>, 0>("v1 64x128x16 1x4 bpc6", c, U, V, M, reps);
+            run<GemmShape<64, 64, 16, 2, 2, 8>, 0>("v1 64x64x16 2x2 bpc8", c, U, V, M, reps);
+            run<GemmShape<64, 256, 16, 1, 4, 3>, 0>("v1 64x256x16 1x4 bpc3", c, U, V, M, reps);
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 output of tools/profile.sh into a small markdown table (per kernel: calls, avg/total time,
+PMC counters averaged per dispatch).  Usage: summarize_prof.py <prof_dir>"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name
+    for a, b in (("fhip::", ""), ("void ", ""), ("GemmShape", "Shape"), ("(anonymous namespace)::", "")):
+        n = n.replace(a, b)
+    return n[:110]
+
+
+def main(d):
+    print(f"# rocprofv3 summary of `{os.path.basename(d.rstrip('/'))}`\n")
+    stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        print("## kernel-trace --stats (all dispatches of the command, warm-up and per-layer timing passes included)\n")
+        print("| kernel | calls | total ms | avg us | min us | max us | % |")
+        print("|---|---|---|---|---|---|---|")
+        rows = list(csv.DictReader(open(stats[0])))
+        for r in rows[:25]:
+            print(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
+                  f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
+        print()
+    # PMC passes
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r.get("Kernel_Name", ""))
+            c = r.get("Counter_Name", "")
+            v = float(r.get("Counter_Value", 0) or 0)
+            a = agg[k][c]
+            a[0] += v
+            a[1] += 1
+    if agg:
+        counters = sorted({c for k in agg for c in agg[k]})
+        print("## PMC counters, average per dispatch (separate passes per counter group; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them)\n")
+        print("| kernel | " + " | ".join(counters) + " |")
+        print("|---|" + "---|" * len(counters))
+        for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
+            print(f"| `{k}` | " + " | ".join(f"{agg[k][c][0] / max(agg[k][c][1], 1):.4g}" if c in agg[k] else "" for c in counters) + " |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -14,6 +14,8 @@
 //     writes them with one float4 store -- output planes of a chunk are contiguous too.
 // Everything else (other kernel sizes, strides, widths not divisible by 4, planes larger than LDS, the
 // global-kernel case) goes through a generic one-output-per-lane kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fhip
@@ -50,10 +52,27 @@ __global__ __launch_bounds__(256) void depthwise3x3_lds_kernel(const DwParams q)
         const int np = min(q.planes_per_chunk, q.planes - plane0);
         // ---- stage: global -> LDS, 16 B per lane, fully coalesced -----------------------------------
         {
+            // 8 independent 16-byte loads per lane in flight before the first LDS write (a plain copy loop is
+            // compiled load -> wait -> store and serialises on the HBM round trip: measured 3.4 -> TB/s)
             const float4* src = reinterpret_cast<const float4*>(q.in + (size_t)plane0 * HW);
             float4* dst = reinterpret_cast<float4*>(tile);
             const int n4 = (np * HW) >> 2;
-            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+            for (int i0 = tid; i0 < n4; i0 += 256 * 8)
+            {
+                float4 v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                {
+                    const int i = i0 + b * 256;
+                    v[b] = src[min(i, n4 - 1)];
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                {
+                    const int i = i0 + b * 256;
+                    if (i < n4) dst[i] = v[b];
+                }
+            }
             for (int i = tid; i < np * 12; i += 256)
             {
                 const int pl = i / 12, e = i - pl * 12;
@@ -126,6 +145,193 @@ __global__ __launch_bounds__(256) void depthwise3x3_lds_kernel(const DwParams q)
     }
 }
 
+// Direct 3x3 form: no LDS, every lane produces a VX-wide x R-high output patch straight from global memory.
+// Per input row it issues the aligned VX-wide centre vector(s) plus the two halo scalars (which hit lines its
+// neighbours fetch anyway); all (R*S+2) rows' loads are issued before the first FMA, the patch leaves as R
+// VX-wide stores.  No barrier, <= 64 VGPRs, so 8 waves per SIMD hide the HBM latency the way a plain copy
+// kernel does; the vertical halo rows are re-read through L1/L2, not HBM.
+template <int VX>
+struct DwVec;
+template <>
+struct DwVec<4>
+{
+    typedef float4 type;
+    static __device__ void unpack(const float4& v, float* o)
+    {
+        o[0] = v.x;
+        o[1] = v.y;
+        o[2] = v.z;
+        o[3] = v.w;
+    }
+    static __device__ float4 pack(const float* o) { return make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <>
+struct DwVec<2>
+{
+    typedef float2 type;
+    static __device__ void unpack(const float2& v, float* o)
+    {
+        o[0] = v.x;
+        o[1] = v.y;
+    }
+    static __device__ float2 pack(const float* o) { return make_float2(o[0], o[1]); }
+};
+template <>
+struct DwVec<1>
+{
+    typedef float type;
+    static __device__ void unpack(const float& v, float* o) { o[0] = v; }
+    static __device__ float pack(const float* o) { return o[0]; }
+};
+
+template <int S, int VX, int R>
+__global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams q, int yblocks, int xvecs, long long total)
+{
+    typedef typename DwVec<VX>::type vec_t;
+    constexpr int ROWS = (R - 1) * S + 3; // input rows of the patch
+    constexpr int SPAN = (VX - 1) * S + 3; // input columns of the patch: xb-1 .. xb+SPAN-2
+    constexpr int NV = (SPAN - 2 + VX - 1) / VX; // aligned centre vectors covering xb .. xb+SPAN-3
+    const int HW = q.H * q.W, OHW = q.OH * q.OW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+    {
+        const int xq = (int)(idx % xvecs);
+        const long long t = idx / xvecs;
+        const int yb = (int)(t % yblocks);
+        const int plane = (int)(t / yblocks);
+        const int c = plane % q.C;
+        const int ox0 = xq * VX, oy0 = yb * R;
+        const int xb = ox0 * S; // centre starts here; the left halo tap is xb-1 (pad_left == 1)
+        const float* ip = q.in + (size_t)plane * HW;
+
+        float x[ROWS][NV * VX + 2]; // x[r][j] = input(row r, column xb - 1 + j)
+        bool rok[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+        {
+            const int y = oy0 * S - q.PT + r;
+            rok[r] = (unsigned)y < (unsigned)q.H;
+            const float* row = ip + (size_t)(rok[r] ? y : 0) * q.W;
+            x[r][0] = row[max(xb - 1, 0)];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+            {
+                const int xc = xb + v * VX; // aligned; clamp whole vectors that start past the row
+                const vec_t cv = *reinterpret_cast<const vec_t*>(row + min(xc, q.W - VX));
+                DwVec<VX>::unpack(cv, &x[r][1 + v * VX]);
+                if (xc >= q.W)
+                {
+#pragma unroll
+                    for (int e = 0; e < VX; ++e) x[r][1 + v * VX + e] = 0.f;
+                }
+            }
+            x[r][NV * VX + 1] = row[min(xb + NV * VX, q.W - 1)];
+        }
+        float w[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) w[e] = q.w[c * 9 + e];
+        const float b = q.has_bias ? q.bias[c] : 0.f;
+        const bool lok = xb > 0;
+        const bool rrok = xb + NV * VX < q.W;
+        float* op = q.out + (size_t)plane * OHW + (size_t)oy0 * q.OW + ox0;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+        {
+            float acc[VX];
+#pragma unroll
+            for (int e = 0; e < VX; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+            {
+                const int r = j * S + m;
+                if (!rok[r]) continue;
+#pragma unroll
+                for (int e = 0; e < VX; ++e)
+#pragma unroll
+                    for (int n = 0; n < 3; ++n)
+                    {
+                        const int jx = e * S + n; // column index into x[r][]
+                        float v = x[r][jx];
+                        if (jx == 0) v = lok ? v : 0.f;
+                        if (jx == NV * VX + 1) v = rrok ? v : 0.f;
+                        acc[e] += v * w[m * 3 + n];
+                    }
+            }
+            if (oy0 + j < q.OH)
+            {
+                float o[VX];
+#pragma unroll
+                for (int e = 0; e < VX; ++e) o[e] = apply_act(acc[e] + b, q.relu);
+                *reinterpret_cast<vec_t*>(op + (size_t)j * q.OW) = DwVec<VX>::pack(o);
+            }
+        }
+    }
+}
+
+// Small planes of any shape (7x7, 14x14 stride 2, 5x5 kernels ...): same chunk-of-whole-planes staging, then ONE
+// output per lane with lanes along the flattened output index, so the LDS reads of a wave are consecutive
+// addresses (stride SW) and the global stores are consecutive dwords.  planes_per_chunk is a multiple of 4,
+// which keeps every chunk 16-byte aligned whatever H*W is.
+__global__ __launch_bounds__(256) void depthwise_lds_scalar_kernel(const DwParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = q.H * q.W, OHW = q.OH * q.OW, KK = q.KH * q.KW;
+    float* tile = smem;                                                     // [planes_per_chunk][H][W]
+    float* wl = smem + (((size_t)q.planes_per_chunk * HW + 3) & ~(size_t)3); // [planes_per_chunk][KK + 1]
+    const int tid = threadIdx.x;
+    const int chunks = (q.planes + q.planes_per_chunk - 1) / q.planes_per_chunk;
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
+    {
+        const int plane0 = chunk * q.planes_per_chunk;
+        const int np = min(q.planes_per_chunk, q.planes - plane0);
+        const int nf = np * HW;
+        {
+            const float* srcf = q.in + (size_t)plane0 * HW; // 16-byte aligned: plane0 % 4 == 0
+            const float4* src = reinterpret_cast<const float4*>(srcf);
+            float4* dst = reinterpret_cast<float4*>(tile);
+            const int n4 = nf >> 2;
+            for (int i0 = tid; i0 < n4; i0 += 256 * 8)
+            {
+                float4 v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[b] = src[min(i0 + b * 256, n4 - 1)];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (i0 + b * 256 < n4) dst[i0 + b * 256] = v[b];
+            }
+            for (int i = (n4 << 2) + tid; i < nf; i += 256) tile[i] = srcf[i];
+            for (int i = tid; i < np * (KK + 1); i += 256)
+            {
+                const int pl = i / (KK + 1), e = i - pl * (KK + 1);
+                const int c = (plane0 + pl) % q.C;
+                wl[i] = e < KK ? q.w[(size_t)c * KK + e] : (q.has_bias ? q.bias[c] : 0.f);
+            }
+        }
+        __syncthreads();
+        const int nout = np * OHW;
+        float* obase = q.out + (size_t)plane0 * OHW;
+        for (int idx = tid; idx < nout; idx += 256)
+        {
+            const int pl = idx / OHW, r = idx - pl * OHW;
+            const int oy = r / q.OW, ox = r - oy * q.OW;
+            const float* ip = tile + (size_t)pl * HW;
+            const float* wp = wl + pl * (KK + 1);
+            float s = 0.f;
+            for (int m = 0; m < q.KH; ++m)
+            {
+                const int y = oy * q.SH - q.PT + m;
+                if ((unsigned)y >= (unsigned)q.H) continue;
+                for (int n = 0; n < q.KW; ++n)
+                {
+                    const int x = ox * q.SW - q.PL + n;
+                    if ((unsigned)x < (unsigned)q.W) s += ip[y * q.W + x] * wp[m * q.KW + n];
+                }
+            }
+            obase[idx] = apply_act(s + wp[KK], q.relu);
+        }
+        __syncthreads();
+    }
+}
+
 // Generic path: one output per lane, lanes along the flattened (plane, oy, ox) index.
 __global__ __launch_bounds__(256) void depthwise_generic_kernel(const DwParams q, long long total)
 {
@@ -190,7 +396,36 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     const bool fast = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1 && (q.W % 4) == 0 &&
                       (q.OW % 4) == 0 && q.OW * q.SW <= q.W && q.W >= 4 && HW + 12 <= kDwLdsFloats;
     StageTimer tm(FHIP_STAGE_DEPTHWISE, s);
-    if (fast)
+    // measurement switch: FHIP_DW_PATH=lds forces the LDS-staged kernels, =direct the no-LDS one (default: direct)
+    static const int dw_path = [] {
+        const char* e = getenv("FHIP_DW_PATH");
+        return (e && e[0] == 'l') ? 1 : 0;
+    }();
+    const bool k3 = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1;
+    if (k3 && dw_path == 0)
+    {
+        const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
+        const int R = q.SH == 1 ? 4 : 2;
+        const int yblocks = ceil_div(q.OH, R), xvecs = q.OW / vx;
+        const long long total = planes * yblocks * xvecs;
+        const int grid = (int)min((long long)256 * 32, (total + 255) / 256);
+#define FHIP_DW_LAUNCH(S_, VX_, R_) \
+    hipLaunchKernelGGL((depthwise3x3_direct_kernel<S_, VX_, R_>), dim3(grid), dim3(256), 0, s, q, yblocks, xvecs, total)
+        if (q.SH == 1)
+        {
+            if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
+            else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
+            else FHIP_DW_LAUNCH(1, 1, 4);
+        }
+        else
+        {
+            if (vx == 4) FHIP_DW_LAUNCH(2, 4, 2);
+            else if (vx == 2) FHIP_DW_LAUNCH(2, 2, 2);
+            else FHIP_DW_LAUNCH(2, 1, 2);
+        }
+#undef FHIP_DW_LAUNCH
+    }
+    else if (fast)
     {
         q.planes_per_chunk = min(q.planes, kDwLdsFloats / (HW + 12));
         const int chunks = ceil_div(q.planes, q.planes_per_chunk);
@@ -200,6 +435,15 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
             hipLaunchKernelGGL(depthwise3x3_lds_kernel<1>, dim3(grid), dim3(256), lds, s, q);
         else
             hipLaunchKernelGGL(depthwise3x3_lds_kernel<2>, dim3(grid), dim3(256), lds, s, q);
+    }
+    else if (4 * (HW + q.KH * q.KW + 1) + 4 <= kDwLdsFloats)
+    {
+        // at least 4 whole planes fit: LDS-staged one-output-per-lane path, chunks of a multiple of 4 planes
+        const int per_plane = HW + q.KH * q.KW + 1;
+        q.planes_per_chunk = max(4, min(round_up(q.planes, 4), (kDwLdsFloats - 4) / per_plane / 4 * 4));
+        const int chunks = ceil_div(q.planes, q.planes_per_chunk);
+        const size_t lds = ((((size_t)q.planes_per_chunk * HW + 3) & ~(size_t)3) + (size_t)q.planes_per_chunk * (q.KH * q.KW + 1)) * sizeof(float);
+        hipLaunchKernelGGL(depthwise_lds_scalar_kernel, dim3(min(chunks, 256 * 8)), dim3(256), lds, s, q);
     }
     else
     {

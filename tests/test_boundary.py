@@ -1,0 +1,163 @@
+"""The drop-in boundary without a GPU: the C-ABI library loads, exports every symbol include/feather_hip/feather_hip.h
+declares, its pure host entry points (selection, sizing, dims) agree with the reference contract, the C++ host mirror
+(include/booster/booster.h) compiles and links the way feather::ConvLayer uses it, and the product never touches oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+import oracle
+from helpers import golden_cases
+from oracle import conv_geom
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "feather_hip", "feather_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import feathercnn_amd
+    from feathercnn_amd import _lib
+    if not os.path.exists(_lib.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return feathercnn_amd.load_library()
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"FHIP_API\s+[\w\s\*]+?\b(fhip_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    from feathercnn_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in feather_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "python binding table and header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (fhip_\w+)", out))
+    assert exported == set(syms), f"exported-but-undeclared or missing: {exported ^ set(syms)}"
+
+
+def test_struct_layout_matches_reference_field_order():
+    from feathercnn_amd import _lib
+    want = ["output_channels", "input_channels", "input_h", "input_w", "kernel_h", "kernel_w", "output_h", "output_w", "stride_h",
+            "stride_w", "pad_left", "pad_bottom", "pad_right", "pad_top", "group", "bias_term", "activation"]  # booster.h:59-77
+    assert [f[0] for f in _lib.fhip_conv_param._fields_] == want
+    assert ctypes.sizeof(_lib.fhip_conv_param) == 17 * 4
+
+
+def _param(g, batch=1):
+    from feathercnn_amd import ConvParam
+    p = ConvParam(output_channels=g.oc, input_channels=g.ic, input_h=g.ih, input_w=g.iw, kernel_h=g.kh, kernel_w=g.kw,
+                  stride_h=g.sh, stride_w=g.sw, pad_left=g.pl, pad_right=g.pr, pad_top=g.pt, pad_bottom=g.pb, group=g.group,
+                  bias_term=bool(g.bias), activation=g.act, batch=batch)
+    p.AssignOutputDim()
+    return p
+
+
+def test_select_algo_and_dims_match_oracle(lib, port):
+    from feathercnn_amd import ConvBooster
+    geoms = [c[1] for c in golden_cases()] + [conv_geom(64, 64, 8, 3, 1, 1), conv_geom(64, 66, 56, 3, 1, 1), conv_geom(3, 64, 224, 3, 1, 1),
+                                             conv_geom(1, 4, 10, 3, 1, 1), conv_geom(0 + 8, 8, 16, 3, 0 + 1, 1, group=0 + 1)]
+    for g in geoms:
+        p = _param(g)
+        assert (p.output_channels, p.output_h, p.output_w) == port.output_dims(g)
+        assert p.GetFLOPS() == port.flops(g)
+        b = ConvBooster()
+        assert b.SelectAlgo(p) == 0
+        assert b.algo == port.select_algo(g), g
+    # defaults: group / stride 0 -> 1 (booster.h:116-118)
+    from feathercnn_amd import ConvParam
+    q = ConvParam(output_channels=4, input_channels=4, input_h=10, input_w=10, kernel_h=3, kernel_w=3)
+    q.AssignOutputDim()
+    assert (q.group, q.stride_h, q.stride_w, q.output_h, q.output_w) == (1, 1, 1, 8, 8)
+
+
+def test_unsupported_and_error_codes(lib):
+    from feathercnn_amd import (SGECONV, WINOGRADF23, WINOGRADF63FUSED, ConvBooster, FeatherHipError)
+    b = ConvBooster()
+    assert b.SelectAlgo(_param(conv_geom(8, 8, 16, 3, 1, 1, group=2))) == -1  # partial group: -1, avx/booster.cpp:304-308
+    assert "group" in lib.fhip_last_error().decode().lower()
+    with pytest.raises(FeatherHipError):
+        b.GetBufferSize(_param(conv_geom(8, 8, 16, 3, 1, 1)))  # nothing bound
+    for a in (SGECONV, WINOGRADF23, WINOGRADF63FUSED):
+        assert b.ForceSelectAlgo(a) == -1
+    sz = ctypes.c_size_t()
+    from feathercnn_amd import _lib
+    c = _param(conv_geom(8, 8, 16, 3, 1, 1))._c()
+    assert lib.fhip_conv_get_buffer_size(ctypes.byref(c), 2, 1, ctypes.byref(sz), ctypes.byref(sz)) == -1  # SGECONV
+    assert lib.fhip_conv_get_buffer_size(ctypes.byref(c), 4, 0, ctypes.byref(sz), ctypes.byref(sz)) == -2  # batch 0: bad arg
+
+
+def test_buffer_sizes_are_pure_and_scale_with_batch(lib):
+    from feathercnn_amd import DEPTHWISE, IM2COL, WINOGRADF63, ConvBooster, booster
+    p1, p8 = _param(conv_geom(64, 128, 56, 3, 1, 1), 1), _param(conv_geom(64, 128, 56, 3, 1, 1), 8)
+    b = ConvBooster()
+    b.SelectAlgo(p1)
+    assert b.algo == WINOGRADF63
+    buf1, pk1 = b.GetBufferSize(p1)
+    buf8, pk8 = b.GetBufferSize(p8)
+    assert (buf1, pk1) == b.GetBufferSize(p1)  # pure
+    assert pk1 == pk8 == 64 * 64 * 128 * 4     # U[64][C][K] fp32 (the reference packs the same 64*C*K floats, avx/booster.cpp:194)
+    pl1, pl8 = booster.winograd_plan(p1), booster.winograd_plan(p8)
+    assert pl1.tiles_x == pl1.tiles_y == 10 and pl1.tiles_per_image == 100 and pl8.columns == 800
+    assert buf8 == pl8.v_bytes + pl8.m_bytes and buf8 > 7 * buf1 * 0.8
+    assert pl8.columns_padded % 128 == 0 and pl8.v_offset_bytes == 0 and pl8.m_offset_bytes == pl8.v_bytes
+    # the reference's own scratch for ONE image (float counts, avx/booster.cpp:178-197) has the same V/M terms: 64*T*C + 64*T*K
+    if oracle.have_ref():
+        ref_buf, ref_pk = oracle.ref().buffer_size(conv_geom(64, 128, 56, 3, 1, 1))
+        assert ref_pk * 4 == pk1
+        assert ref_buf >= 64 * 100 * (64 + 128)
+    b.ForceSelectAlgo(IM2COL)
+    assert b.GetBufferSize(p8)[0] == 0  # the column matrix is never materialised
+    d = _param(conv_geom(32, 32, 28, 3, 1, 1, group=32), 4)
+    b.SelectAlgo(d)
+    assert b.algo == DEPTHWISE and b.GetBufferSize(d) == (0, 32 * 9 * 4)
+
+
+def test_no_device_is_reported_not_faked(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    name = ctypes.create_string_buffer(64)
+    cu, ldsb = ctypes.c_int(), ctypes.c_int()
+    assert lib.fhip_device_info(name, 64, ctypes.byref(cu), ctypes.byref(ldsb)) == -4  # FHIP_E_NODEVICE
+    from feathercnn_amd import ConvLayer, FeatherHipError
+    p = _param(conv_geom(8, 8, 16, 3, 1, 1))
+    with pytest.raises((FeatherHipError, RuntimeError, AssertionError)):
+        ConvLayer(p, torch.zeros(8, 8, 3, 3))  # host tensors: there is no CPU path
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "feathercnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f"{f} imports the oracle"
+                assert "conv_port" not in txt and "libfeather_ref" not in txt and "oracle/" not in txt, f"{f} references the oracle"
+    hdr = open(HEADER).read() + open(os.path.join(ROOT, "include", "booster", "booster.h")).read()
+    assert "oracle" not in hdr
+    proc = subprocess.run([sys.executable, "-c", "import sys; import feathercnn_amd; import feathercnn_amd.nets, feathercnn_amd.shard; "
+                           "assert 'oracle' not in sys.modules"], cwd=ROOT, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+
+
+def test_cpp_host_api_compiles_and_runs_like_convlayer(lib, tmp_path):
+    """include/booster/booster.h is source-compatible with how feather::ConvLayer drives ConvBooster (conv_layer.h:92-172)."""
+    from feathercnn_amd import _lib
+    src = os.path.join(ROOT, "tests", "cpp", "host_api_test.cpp")
+    exe = str(tmp_path / "host_api_test")
+    libdir = os.path.dirname(_lib.lib_path())
+    cmd = ["g++", "-std=c++11", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir, "-lfeather_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host api ok" in out.stdout

@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: two gloo ranks shard a batch and receive rank 0's weights through the same helper bench.py uses on
+RCCL (feathercnn_amd/shard.py).  The data path itself has no collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from feathercnn_amd.shard import broadcast_weights, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)  # every rank starts from DIFFERENT weights
+        weights = [torch.rand(8, 4, 3, 3, generator=g), torch.rand(8, generator=g), None, torch.rand(16, 8, 1, 1, generator=g)]
+        nbytes = broadcast_weights(weights, src=0)
+        lo, hi = shard_range(10, rank, world)
+        batch = torch.arange(10 * 3, dtype=torch.float32).reshape(10, 3)[lo:hi]
+        digest = float(sum(t.double().sum() for t in weights if t is not None))
+        # a data-path-free reduction only to CHECK the shards (the product path has no collective)
+        s = torch.tensor([batch.sum().item()], dtype=torch.float64)
+        dist.all_reduce(s)
+        q.put((rank, nbytes, digest, lo, hi, float(s.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_broadcast_and_shard():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, nb0, d0, lo0, hi0, s0), (r1, nb1, d1, lo1, hi1, s1) = res
+    assert nb0 == nb1 == (8 * 4 * 9 + 8 + 16 * 8) * 4
+    assert d0 == d1, "rank 1 did not receive rank 0's weights"
+    g = torch.Generator().manual_seed(100)
+    want = float(torch.rand(8, 4, 3, 3, generator=g).double().sum() + torch.rand(8, generator=g).double().sum()
+                 + torch.rand(16, 8, 1, 1, generator=g).double().sum())
+    assert abs(d0 - want) < 1e-9
+    assert (lo0, hi0, lo1, hi1) == (0, 5, 5, 10)
+    assert s0 == s1 == float(np.arange(30).sum())

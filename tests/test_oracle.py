@@ -1,0 +1,77 @@
+"""The CPU checkers themselves (no GPU): the plain-C restatement (oracle/conv_port.c) against the committed golden
+vectors produced by the REAL reference, against an fp64 direct convolution, and -- where its .so is present -- the
+real reference against the same fixtures.  This is what pins the oracle (task rule: an unpinned oracle caps parity)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden_cases
+from oracle import conv_geom, nerr, synth
+
+CASES = golden_cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_port_matches_reference_golden(case, port):
+    name, g, batch, algo, x, w, b, y, sel = case
+    got = port.forward(g, x, w, b, algo=algo)
+    assert got.shape == y.shape
+    # fp32 summation order differs (reference: blocked AVX2 + -ffast-math); Winograd error floor ~1e-5
+    assert nerr(got, y) <= 5e-5, name
+    assert port.select_algo(g) == sel, "restated SelectAlgo disagrees with the reference"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_reference_reproduces_golden(case):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built here")
+    name, g, batch, algo, x, w, b, y, sel = case
+    got = oracle.ref().forward(g, x, w, b, algo=algo)
+    assert nerr(got, y) <= 1e-6, name
+    assert oracle.ref().select_algo(g) == sel
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] != oracle.NAIVE], ids=[c[0] for c in CASES if c[3] != oracle.NAIVE])
+def test_golden_vs_fp64_direct(case, port):
+    """The reference's own accuracy against an fp64 direct convolution (<= 2.8e-5 Winograd, ~1e-6 others)."""
+    name, g, batch, algo, x, w, b, y, sel = case
+    assert nerr(y, port.direct_f64(g, x, w, b)) <= 5e-5
+
+
+SELECT = [
+    # (geom, expected booster::ConvAlgo) -- ConvBooster::SelectAlgo, reference avx/booster.cpp:283-310
+    (conv_geom(64, 64, 56, 3, 1, 1), oracle.WINOGRADF63),
+    (conv_geom(64, 64, 9, 3, 1, 1), oracle.WINOGRADF63),
+    (conv_geom(64, 64, 8, 3, 1, 1), oracle.IM2COL),       # input_h > 8 required
+    (conv_geom(3, 64, 224, 3, 1, 1), oracle.IM2COL),      # input_channels % 4 (AVX rule)
+    (conv_geom(64, 66, 56, 3, 1, 1), oracle.IM2COL),      # output_channels % 4
+    (conv_geom(64, 64, 56, 3, 2, 1), oracle.IM2COL),      # stride
+    (conv_geom(64, 64, 56, 1, 1, 0), oracle.IM2COL),
+    (conv_geom(3, 64, 224, 7, 2, 3), oracle.IM2COL),
+    (conv_geom(32, 32, 112, 3, 1, 1, group=32), oracle.DEPTHWISE),
+    (conv_geom(1, 4, 10, 3, 1, 1, group=1), oracle.DEPTHWISE),  # group == input_channels == 1 is tested FIRST by the reference
+    (conv_geom(8, 8, 16, 3, 1, 1, group=2), -1),          # partial group -> -1
+]
+
+
+@pytest.mark.parametrize("g,want", SELECT, ids=[f"{g.ic}-{g.oc}-{g.ih}-k{g.kh}s{g.sh}g{g.group}" for g, _ in SELECT])
+def test_select_algo_table(g, want, port):
+    assert port.select_algo(g) == want
+    if oracle.have_ref():
+        assert oracle.ref().select_algo(g) == want
+
+
+def test_output_dims_floor_and_depthwise(port):
+    # floor output dims and depthwise output_channels = input_channels (booster.h:113-125)
+    assert port.output_dims(conv_geom(3, 64, 224, 7, 2, 3)) == (64, 112, 112)
+    assert port.output_dims(conv_geom(3, 64, 224, 3, 2, 0)) == (64, 111, 111)
+    assert port.output_dims(conv_geom(8, 99, 15, 3, 2, 1, group=8)) == (8, 8, 8)
+    assert port.flops(conv_geom(64, 64, 56, 3, 1, 1)) == 2.0 * 64 * 64 * 56 * 56 * 9
+
+
+def test_port_sweep_vs_fp64(port):
+    """Shapes of the survey probe through the restatement's own dispatch."""
+    for g in [conv_geom(16, 16, 9, 3, 1, 1), conv_geom(8, 8, 31, 3, 1, 1, w=17), conv_geom(16, 64, 27, 3, 1, 1),
+              conv_geom(48, 24, 13, 1, 1, 0), conv_geom(3, 8, 33, 7, 2, 3), conv_geom(12, 12, 21, 3, 2, 1, group=12)]:
+        x, w, b = synth(g, 2, seed=7)
+        assert nerr(port.forward(g, x, w, b), port.direct_f64(g, x, w, b)) <= 5e-5

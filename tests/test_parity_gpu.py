@@ -137,3 +137,179 @@ def test_unsupported(cuda):
     assert b.SelectAlgo(p) == -1  # partial group, avx/booster.cpp:304-308
     for a in (SGECONV, WINOGRADF23, WINOGRADF63FUSED):
         assert b.ForceSelectAlgo(a) == -1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# committed golden vectors (outputs of the real reference, tests/golden/make_golden.py)
+from helpers import golden_cases  # noqa: E402
+
+_GOLD = golden_cases()
+
+
+@pytest.mark.parametrize("case", _GOLD, ids=[c[0] for c in _GOLD])
+def test_golden_fixtures(case, cuda):
+    name, g, batch, algo, x, w, b, y, sel = case
+    got, used = run_gpu(g, x, w, b, cuda, None if algo < 0 else algo)
+    assert used == (sel if algo < 0 else algo)
+    assert nerr(got, y) <= TOL, name
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stage-level entry points (the reference's free functions: transformKernel_F6x6_3x3, input transform, TensorGEMM, output
+# transform) against a numpy restatement of the same matrices
+_G = np.array([[1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45], [1 / 90, -1 / 45, 2 / 45],
+               [1 / 45, 1 / 90, 1 / 180], [1 / 45, -1 / 90, 1 / 180], [0, 0, 1]], np.float64)
+_BT = np.array([[1, 0, -5.25, 0, 5.25, 0, -1, 0], [0, 1, 1, -4.25, -4.25, 1, 1, 0], [0, -1, 1, 4.25, -4.25, -1, 1, 0],
+                [0, .5, .25, -2.5, -1.25, 2, 1, 0], [0, -.5, .25, 2.5, -1.25, -2, 1, 0], [0, 2, 4, -2.5, -5, .5, 1, 0],
+                [0, -2, 4, 2.5, -5, -.5, 1, 0], [0, -1, 0, 5.25, 0, -5.25, 0, 1]], np.float64)
+_AT = np.array([[1, 1, 1, 1, 1, 32, 32, 0], [0, 1, -1, 2, -2, 16, -16, 0], [0, 1, 1, 4, 4, 8, 8, 0], [0, 1, -1, 8, -8, 4, -4, 0],
+                [0, 1, 1, 16, 16, 2, 2, 0], [0, 1, -1, 32, -32, 1, -1, 1]], np.float64)
+
+
+def test_winograd_stage_api(cuda):
+    import ctypes
+
+    import torch
+
+    from feathercnn_amd import ConvParam, _lib, booster
+    lib = _lib.load_library()
+    g = conv_geom(12, 20, 17, 3, 1, 1, w=23)
+    n = 3
+    x, w, b = synth(g, n, seed=5)
+    p = ConvParam.make(g.ic, g.oc, g.ih, 3, 1, 1, w=g.iw, batch=n)
+    pl = booster.winograd_plan(p)
+    T, TX, P, Pp = pl.tiles_per_image, pl.tiles_x, pl.columns, pl.columns_padded
+    Cp, Kp = pl.in_channels_padded, pl.out_channels_padded
+    c = p._c()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dv = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    xt, wt, bt = (torch.from_numpy(a).to(cuda) for a in (x, w, b))
+    U = torch.full((64, Cp, Kp), float("nan"), device=cuda)
+    V = torch.full((64, g.ic, Pp), float("nan"), device=cuda)
+    M = torch.full((64, g.oc, Pp), float("nan"), device=cuda)
+    out = torch.full((n, g.oc, p.output_h, p.output_w), float("nan"), device=cuda)
+    assert lib.fhip_winograd_f63_transform_kernel(ctypes.byref(c), dv(U), dv(wt), st) == 0
+    assert lib.fhip_winograd_f63_input_transform(ctypes.byref(c), n, dv(V), dv(xt), st) == 0
+    assert lib.fhip_winograd_f63_tile_gemm(ctypes.byref(c), n, dv(M), dv(U), dv(V), st) == 0
+    assert lib.fhip_winograd_f63_output_transform(ctypes.byref(c), n, dv(out), dv(M), dv(bt), st) == 0
+    torch.cuda.synchronize()
+    # U = G g G^T, zero padded
+    Uref = np.einsum("ia,kcab,jb->ijck", _G, w.astype(np.float64), _G).reshape(64, g.ic, g.oc)
+    Ug = U.cpu().numpy()
+    assert nerr(Ug[:, :g.ic, :g.oc], Uref) <= 1e-6
+    assert np.all(Ug[:, g.ic:, :] == 0) and np.all(Ug[:, :, g.oc:] == 0)
+    # V = B^T d B on zero-padded 8x8 patches at stride 6, column p = n*T + ty*TX + tx
+    xp = np.zeros((n, g.ic, 6 * pl.tiles_y + 2, 6 * TX + 2))
+    xp[:, :, 1:1 + g.ih, 1:1 + g.iw] = x
+    patches = np.stack([xp[:, :, 6 * ty:6 * ty + 8, 6 * tx:6 * tx + 8] for ty in range(pl.tiles_y) for tx in range(TX)], axis=2)
+    Vref = np.einsum("ia,nctab,jb->ijcnt", _BT, patches, _BT).reshape(64, g.ic, P)
+    assert nerr(V.cpu().numpy()[:, :, :P], Vref) <= 1e-5
+    # M = U V per frequency point
+    Mref = np.einsum("xck,xcp->xkp", Uref, Vref)
+    assert nerr(M.cpu().numpy()[:, :, :P], Mref) <= 1e-5
+    # Y = A^T M A + bias, ReLU, clipped
+    Y = np.einsum("ai,ijknt,bj->nktab", _AT, Mref.reshape(8, 8, g.oc, n, T), _AT)
+    full = np.zeros((n, g.oc, 6 * pl.tiles_y, 6 * TX))
+    for t in range(T):
+        ty, tx = divmod(t, TX)
+        full[:, :, 6 * ty:6 * ty + 6, 6 * tx:6 * tx + 6] = Y[:, :, t]
+    yref = np.maximum(full[:, :, :p.output_h, :p.output_w] + b[None, :, None, None], 0)
+    assert nerr(out.cpu().numpy(), yref) <= 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes through size-independent properties (the CPU oracle would take minutes there)
+def _layer(dev, ic, oc, h, k, s, p, group, batch, bias=True, act=1, algo=None, seed=0):
+    import torch
+
+    from feathercnn_amd import ConvLayer, ConvParam
+    prm = ConvParam.make(ic, oc, h, k, s, p, group=group, bias=bias, act=act, batch=batch)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    cpg = ic // group
+    w = (torch.rand((prm.output_channels, cpg, k, k), device=dev, generator=gen) * 2 - 1) / (cpg * k * k) ** 0.5
+    b = (torch.rand((prm.output_channels,), device=dev, generator=gen) * 2 - 1) * 0.1 if bias else None
+    return ConvLayer(prm, w, b, algo=algo), w, b
+
+
+FULL = [("vgg_conv1_2", 64, 64, 224, 3, 1, 1, 1, 32), ("vgg_conv3_2", 256, 256, 56, 3, 1, 1, 1, 32), ("vgg_conv5_1", 512, 512, 14, 3, 1, 1, 1, 32),
+        ("r50_1x1", 256, 64, 56, 1, 1, 0, 1, 64), ("r50_proj_s2", 256, 512, 56, 1, 2, 0, 1, 64), ("r50_conv1", 3, 64, 224, 7, 2, 3, 1, 64),
+        ("mb_dw_s1", 32, 32, 112, 3, 1, 1, 32, 256), ("mb_dw_s2", 64, 64, 112, 3, 2, 1, 64, 256), ("mb_dw_14", 512, 512, 14, 3, 1, 1, 512, 256)]
+
+
+@pytest.mark.parametrize("cfg", FULL, ids=[c[0] for c in FULL])
+def test_full_size_properties(cfg, cuda):
+    import torch
+    name, ic, oc, h, k, s, p, group, batch = cfg
+    gen = torch.Generator(device=cuda).manual_seed(11)
+    x1 = torch.rand((batch, ic, h, h), device=cuda, generator=gen) * 2 - 1
+    # (1) determinism: two forwards are bit-identical; (2) the shared scratch arena may hold garbage
+    lyr, w, b = _layer(cuda, ic, oc, h, k, s, p, group, batch)
+    scratch = torch.full((max(lyr.buffer_bytes // 4, 1),), float("nan"), device=cuda)
+    y1 = lyr.Forward(x1, scratch=scratch).clone()
+    scratch.fill_(1e30)
+    y2 = lyr.Forward(x1, scratch=scratch)
+    assert torch.equal(y1, y2)
+    assert torch.isfinite(y1).all()
+    # (3) batch independence: image i of the batch == the same image run alone (the reference is N=1, conv_layer.h:107)
+    one, _, _ = _layer(cuda, ic, oc, h, k, s, p, group, 1)
+    for i in (0, batch - 1):
+        yi = one.Forward(x1[i:i + 1].contiguous())
+        assert float((yi[0] - y1[i]).abs().max()) <= 1e-5 * float(y1[i].abs().max())
+    # (4) sampled fp64 direct convolution at 1500 random output positions
+    prm = lyr.param
+    idx = torch.randint(0, y1.numel(), (1500,), generator=torch.Generator().manual_seed(3))
+    n_, k_, oy, ox = np.unravel_index(idx.numpy(), tuple(y1.shape))
+    xc, wc = x1.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64)
+    bc = b.cpu().numpy().astype(np.float64)
+    cpg = ic // group
+    ref = np.empty(1500)
+    for j in range(1500):
+        c0 = k_[j] if group > 1 else 0
+        acc = bc[k_[j]]
+        for u in range(k):
+            yy = oy[j] * s - p + u
+            if yy < 0 or yy >= h:
+                continue
+            for v in range(k):
+                xx = ox[j] * s - p + v
+                if 0 <= xx < h:
+                    acc += float(np.dot(xc[n_[j], c0:c0 + cpg, yy, xx], wc[k_[j], :, u, v]))
+        ref[j] = max(acc, 0.0)
+    got = y1.cpu().numpy().reshape(-1)[idx.numpy()]
+    assert np.max(np.abs(got - ref)) <= TOL * float(y1.abs().max())
+    # (5) linearity without bias / activation
+    lin, _, _ = _layer(cuda, ic, oc, h, k, s, p, group, batch, bias=False, act=0)
+    x2 = torch.rand((batch, ic, h, h), device=cuda, generator=gen) * 2 - 1
+    lhs = lin.Forward((2.0 * x1 - 3.0 * x2).contiguous())
+    rhs = 2.0 * lin.Forward(x1).clone() - 3.0 * lin.Forward(x2)
+    assert float((lhs - rhs).abs().max()) <= TOL * float(rhs.abs().max())
+
+
+def test_full_size_winograd_vs_implicit_gemm(cuda):
+    """ForceSelectAlgo cross-check at VGG conv4_2 batch 32: two different algorithms, same answer."""
+    import torch
+    a, w, b = _layer(cuda, 512, 512, 28, 3, 1, 1, 1, 32, algo=oracle.WINOGRADF63)
+    c, _, _ = _layer(cuda, 512, 512, 28, 3, 1, 1, 1, 32, algo=oracle.IM2COL)
+    x = torch.rand((32, 512, 28, 28), device=cuda, generator=torch.Generator(device=cuda).manual_seed(2)) * 2 - 1
+    ya, yc = a.Forward(x), c.Forward(x)
+    assert float((ya - yc).abs().max()) <= TOL * float(yc.abs().max())
+
+
+def test_cpp_host_forward(cuda, tmp_path):
+    """The C++ host class (include/booster/booster.h) drives Init + Forward on device buffers exactly like feather::ConvLayer."""
+    import os
+    import shutil
+    import subprocess
+
+    from feathercnn_amd import _lib
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_forward_test")
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.run([hipcc, "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "host_forward_test.cpp"),
+                    "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host forward ok" in out.stdout

@@ -108,6 +108,31 @@ def cpu_baseline(net, procs):
             "single_core_images_per_s": round(1.0 / single, 3), "cpu_model": model, "host_cores": ncpu}
 
 
+def pmc_traffic(net, bound):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/<round>_<net>/traffic.json, written by tools/profile.sh + tools/summarize_prof.py: separate --pmc
+    passes for FETCH_SIZE and WRITE_SIZE, read side doubled per MI355X_MICROARCH.md's gfx950 note).  null if no profile."""
+    tag = {"vgg16": "vgg16", "resnet50": "resnet50", "mobilenet_v1": "mobilenet"}.get(net, net)
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, d, "traffic.json")
+        if d.endswith("_" + tag) and os.path.exists(f):
+            best = f  # the latest round wins
+    if not best:
+        return {"traffic": None}
+    want = "WinoGemmPolicy" if bound == "mfma" else "depthwise"
+    tot, n = 0.0, 0
+    for k, v in json.load(open(best)).items():
+        if want in k:
+            tot += v["hbm_bytes_per_launch"] * v["launches_profiled"]
+            n += v["launches_profiled"]
+    if not n:
+        return {"traffic": None}
+    return {"traffic": round(tot / n), "traffic_unit": "bytes per launch (avg over the kernel's launches)",
+            "traffic_source": os.path.relpath(best, ROOT)}
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -133,24 +158,26 @@ def main():
     layers = nets.NETS[a.net]()
 
     # ---- weights: generated on rank 0, broadcast once over RCCL (the only collective of this path) -------------------
+    from feathercnn_amd.shard import broadcast_weights
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234)
-    t_bcast = 0.0
-    built = []
-    max_scratch, max_out = 0, 0
+    gen.manual_seed(1234 + rank)  # ranks start from DIFFERENT weights: only the broadcast makes them agree
+    raw = []
     for layer in layers:
         name, c, k, h, ks, s, p, g = layer
         prm = nets.layer_param(layer, batch)
         cpg = c // g
         w = (torch.rand((prm.output_channels, cpg, ks, ks), device=dev, generator=gen) * 2 - 1) / (cpg * ks * ks) ** 0.5
         b = (torch.rand((prm.output_channels,), device=dev, generator=gen) * 2 - 1) * 0.1
-        if world > 1:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dist.broadcast(w, 0)
-            dist.broadcast(b, 0)
-            torch.cuda.synchronize()
-            t_bcast += time.perf_counter() - t0
+        raw.append((prm, w, b))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bcast_bytes = broadcast_weights([t for _, w, b in raw for t in (w, b)], src=0)  # ONE flat RCCL broadcast
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    built = []
+    max_scratch, max_out = 0, 0
+    for layer, (prm, w, b) in zip(layers, raw):
+        name, c, k, h, ks, s, p, g = layer
         lyr = ConvLayer(prm, w, b)
         x = torch.rand((batch, c, h, h), device=dev, generator=gen) * 2 - 1
         built.append((layer, prm, lyr, x))
@@ -244,6 +271,8 @@ def main():
                         "note": "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
                                 "sum of their tile-GEMM HIP-event durations"}
         stage_ms = {k: round(v, 4) for k, v in stage_tot.items()}
+        if roofline is not None:
+            roofline.update(pmc_traffic(a.net, roofline["bound"]))
     if world > 1:
         dist.barrier()
 
@@ -260,7 +289,7 @@ def main():
             "roofline": roofline,
         }
         if world > 1:
-            res["weight_broadcast_ms"] = round(t_bcast * 1e3, 3)
+            res["weight_broadcast"] = {"ms": round(t_bcast * 1e3, 3), "bytes": bcast_bytes, "collective": "1 flat RCCL broadcast from rank 0"}
         if not a.no_cpu_baseline and n_gpus == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.net, a.cpu_procs)

@@ -46,5 +46,20 @@ def main(d):
             print(f"| `{k}` | " + " | ".join(f"{agg[k][c][0] / max(agg[k][c][1], 1):.4g}" if c in agg[k] else "" for c in counters) + " |")
 
 
+    # machine-readable digest for bench.py's roofline.traffic: HBM bytes per launch of the hot kernels.
+    # MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+    # stream, so the read side is doubled; WRITE_SIZE is taken as reported; both are KiB.
+    import json
+    dig = {}
+    for k in agg:
+        if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            f = agg[k]["FETCH_SIZE"][0] / max(agg[k]["FETCH_SIZE"][1], 1)
+            w = agg[k]["WRITE_SIZE"][0] / max(agg[k]["WRITE_SIZE"][1], 1)
+            dig[k] = {"launches_profiled": agg[k]["FETCH_SIZE"][1], "fetch_kib_raw": f, "write_kib_raw": w,
+                      "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    with open(os.path.join(d, "traffic.json"), "w") as fo:
+        json.dump(dig, fo, indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])

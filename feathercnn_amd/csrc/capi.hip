@@ -1,6 +1,9 @@
 // capi.hip -- the extern "C" surface declared in include/feather_hip/feather_hip.h: algorithm selection,
 // buffer sizing, Init and Forward dispatch (the GPU counterpart of reference src/booster/avx/booster.cpp),
 // error reporting and per-stage event timing.
+#include <stdlib.h>
+
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -16,12 +19,18 @@ int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, cons
 int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const float* u, const float* v, hipStream_t s);
 int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
                               hipStream_t s);
+int winograd_fused_gemm_output(const fhip_conv_param& p, int batch, float* output, const float* u, const float* v, const float* bias,
+                               hipStream_t s);
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
-                  bool force_no_act, hipStream_t s);
+                  float* buffer, bool force_no_act, hipStream_t s);
+size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch);
 int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* kernel, const float* bias,
                       hipStream_t s);
+
+// Winograd cache blocking: bytes of V + M kept in flight per sub-batch (MiB); measured sweep in DESIGN.md 3.2
+constexpr long kWinoChunkMB = 0;
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -155,7 +164,7 @@ int fhip_conv_get_buffer_size(const fhip_conv_param* p, int algo, int batch, siz
             if (p->group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
             int kdp, kp;
             igemm_packed_dims(*p, &kdp, &kp);
-            *buffer_bytes = 0; // the column matrix is never materialised
+            *buffer_bytes = igemm_buffer_bytes(*p, batch); // no column matrix; split-K partial sums for under-filled grids only
             *packed_bytes = (size_t)kdp * kp * sizeof(float);
             return FHIP_OK;
         }
@@ -203,20 +212,56 @@ int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* outp
     hipStream_t s = (hipStream_t)stream;
     switch (algo)
     {
-        case FHIP_NAIVE: return igemm_forward(*p, batch, output, input, packed, bias, true, s);
-        case FHIP_IM2COL: return igemm_forward(*p, batch, output, input, packed, bias, false, s);
+        case FHIP_NAIVE: return igemm_forward(*p, batch, output, input, packed, bias, buffer, true, s);
+        case FHIP_IM2COL: return igemm_forward(*p, batch, output, input, packed, bias, buffer, false, s);
         case FHIP_DEPTHWISE: return depthwise_forward(*p, batch, output, input, packed, bias, s);
         case FHIP_WINOGRADF63:
         {
             if (!buffer) return fail(FHIP_E_BADARG, "Winograd needs the scratch buffer");
-            fhip_winograd_plan pl;
-            int rc = winograd_plan(*p, batch, &pl);
+            // measurement switches: FHIP_WINO_FUSED=1 forces the fused GEMM + output-transform kernel (measured slower,
+            // DESIGN.md 3.1); FHIP_WINO_CHUNK_MB overrides the sub-batch size of the cache blocking below (0 = off).
+            static const int fused_env = [] {
+                const char* e = getenv("FHIP_WINO_FUSED");
+                return e ? atoi(e) : 0;
+            }();
+            static const long chunk_mb = [] {
+                const char* e = getenv("FHIP_WINO_CHUNK_MB");
+                return e ? atol(e) : (long)kWinoChunkMB;
+            }();
+            // Cache blocking over the batch: V and M of `nb` images are produced and consumed back to back in the same
+            // scratch bytes, so for small enough nb they live in the 256 MiB Infinity Cache instead of making four trips
+            // through HBM (V write, V read, M write, M read = 3 GB per VGG conv1_2 batch of 32).
+            fhip_winograd_plan one;
+            int rc = winograd_plan(*p, 1, &one);
             if (rc) return rc;
-            float* v = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.v_offset_bytes);
-            float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.m_offset_bytes);
-            if ((rc = winograd_input_transform(*p, batch, v, input, s))) return rc;
-            if ((rc = winograd_tile_gemm(*p, batch, m, packed, v, s))) return rc;
-            return winograd_output_transform(*p, batch, output, m, bias, s);
+            const size_t per_image = (size_t)64 * (p->input_channels + p->output_channels) * one.tiles_per_image * sizeof(float);
+            int nb = batch;
+            if (chunk_mb > 0)
+            {
+                const long fit = (long)((size_t)chunk_mb * 1024 * 1024 / (per_image ? per_image : 1));
+                nb = (int)std::max(1L, std::min((long)batch, fit));
+            }
+            const size_t in_img = (size_t)p->input_channels * p->input_h * p->input_w;
+            const size_t out_img = (size_t)p->output_channels * p->output_h * p->output_w;
+            for (int b0 = 0; b0 < batch; b0 += nb)
+            {
+                const int bn = std::min(nb, batch - b0);
+                fhip_winograd_plan pl;
+                if ((rc = winograd_plan(*p, bn, &pl))) return rc;
+                float* v = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.v_offset_bytes);
+                float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.m_offset_bytes);
+                const float* in_b = input + (size_t)b0 * in_img;
+                float* out_b = output + (size_t)b0 * out_img;
+                if ((rc = winograd_input_transform(*p, bn, v, in_b, s))) return rc;
+                if (fused_env)
+                {
+                    if ((rc = winograd_fused_gemm_output(*p, bn, out_b, packed, v, bias, s))) return rc;
+                    continue;
+                }
+                if ((rc = winograd_tile_gemm(*p, bn, m, packed, v, s))) return rc;
+                if ((rc = winograd_output_transform(*p, bn, out_b, m, bias, s))) return rc;
+            }
+            return FHIP_OK;
         }
         default: return fail(FHIP_E_UNSUPPORTED, "This algo is not supported on gfx950");
     }

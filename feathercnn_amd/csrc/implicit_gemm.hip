@@ -8,10 +8,14 @@
 // epilogue fused into the accumulator store.  It serves exactly what AVX SelectAlgo routes to IM2COL
 // (avx/booster.cpp:294-303): 1x1 s1/s2, 7x7 s2, 3x3 with H <= 8 or C % 4 != 0, 3x3 s2; and NAIVE
 // (avx/booster.cpp:28-61, which ignores activation).
+#include <algorithm>
+
 #include "gemm_core.h"
 
 namespace fhip
 {
+
+constexpr int kConvKTile = 16;
 
 struct ConvGemmParams
 {
@@ -26,6 +30,10 @@ struct ConvGemmParams
     int Ntot; // N*OH*OW
     int OHW, HW, KHW;
     int has_bias, relu;
+    // split-K (under-filled grids): the GEMM "batch" index is the K split; split s reduces k-tiles
+    // [s*k_tiles, (s+1)*k_tiles) and writes raw partial sums to partial[s][K][Ntot]; a reduce kernel finishes
+    int split_k;
+    float* partial;
 };
 
 // MODE 0: generic gather (any kernel / stride / pad)
@@ -39,7 +47,7 @@ struct ConvGemmPolicy
     struct ALoad
     {
         const float* base;
-        __device__ ALoad(const Params& p, int, int m4) : base(p.Wt + m4) {}
+        __device__ ALoad(const Params& p, int split, int m4) : base(p.Wt + (size_t)split * p.k_tiles * kConvKTile * p.Kp + m4) {}
         __device__ float4 load(const Params& p, int krow) const
         {
             return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Kp); // Wt zero padded in both dims
@@ -51,9 +59,11 @@ struct ConvGemmPolicy
         const float* ptr[MODE == 2 ? 1 : 4]; // &in[n][0][iy0][ix0] of each of the 4 columns (may point before the plane)
         int iy0[MODE == 0 ? 4 : 1], ix0[MODE == 0 ? 4 : 1];
         unsigned valid; // bit e: column n4+e < Ntot
-        __device__ BLoad(const Params& p, int, int n4)
+        int koff;       // first reduction row of this K split
+        __device__ BLoad(const Params& p, int split, int n4)
         {
             valid = 0;
+            koff = split * p.k_tiles * kConvKTile;
             if (MODE == 2)
             {
                 // 4 consecutive columns stay inside one image (OHW % 4 == 0, n4 % 4 == 0)
@@ -83,8 +93,9 @@ struct ConvGemmPolicy
             }
         }
         // Unconditional loads from clamped addresses; `ok` says which of the 4 values are real (see gemm_core.h).
-        __device__ float4 load(const Params& p, int krow, unsigned& ok) const
+        __device__ float4 load(const Params& p, int krow_in_split, unsigned& ok) const
         {
+            const int krow = krow_in_split + koff;
             const bool kin = krow < p.Kd;
             const int kr = min(krow, p.Kd - 1);
             if (MODE == 2)
@@ -124,8 +135,10 @@ struct ConvGemmPolicy
         float* ptr[4]; // &out[img][0][rem] of each of the 4 columns
         unsigned valid;
         bool wide; // the 4 columns are one aligned 16-byte piece of one image
-        __device__ Store(const Params& p, int, int n4)
+        float* part; // split-K: &partial[split][0][n4]
+        __device__ Store(const Params& p, int split, int n4)
         {
+            part = p.split_k > 1 ? p.partial + (size_t)split * p.K * p.Ntot + n4 : nullptr;
             valid = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -142,6 +155,20 @@ struct ConvGemmPolicy
         __device__ void put4(const Params& p, int m, float4 v) const
         {
             if (m >= p.K) return;
+            if (part)
+            {
+                float* d = part + (size_t)m * p.Ntot;
+                if (valid == 0xfu && (p.Ntot & 3) == 0)
+                    *reinterpret_cast<float4*>(d) = v;
+                else
+                {
+                    if (valid & 1u) d[0] = v.x;
+                    if (valid & 2u) d[1] = v.y;
+                    if (valid & 4u) d[2] = v.z;
+                    if (valid & 8u) d[3] = v.w;
+                }
+                return;
+            }
             if (p.has_bias)
             {
                 const float b = p.bias[m];
@@ -173,7 +200,6 @@ struct ConvGemmPolicy
 
 using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
-constexpr int kConvKTile = 16;
 constexpr int kConvColTile = 128;
 
 static bool conv_small_m(int K) { return K <= 64; }
@@ -183,6 +209,50 @@ void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
     const int Kd = p.input_channels * p.kernel_h * p.kernel_w;
     *kd_padded = round_up(Kd, kConvKTile);
     *k_padded = round_up(p.output_channels, conv_small_m(p.output_channels) ? 64 : 128);
+}
+
+// Split-K decision (pure function of the geometry and the batch: GetBufferSize and Forward must agree).
+// Grids below ~2 blocks per CU leave the matrix pipes idle (ResNet-50's 3x3 and 1x1 layers at 7x7: 196 tiles of 288
+// k-tiles each); the reduction is cut into S equal parts, S a divisor of the k-tile count.
+static int igemm_split(const fhip_conv_param& p, int batch)
+{
+    int kdp, kp;
+    igemm_packed_dims(p, &kdp, &kp);
+    const int bm = conv_small_m(p.output_channels) ? 64 : 128, bn = conv_small_m(p.output_channels) ? 128 : 64;
+    const long long ntot = (long long)batch * p.output_h * p.output_w;
+    const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
+    const int kt = kdp / kConvKTile;
+    if (tiles >= 512 || kt < 16) return 1;
+    const int want = (int)std::min<long long>(8, (768 + tiles - 1) / tiles);
+    int best = 1;
+    for (int s = 2; s <= want; ++s)
+        if (kt % s == 0 && kt / s >= 8) best = s;
+    return best;
+}
+
+size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
+{
+    const int s = igemm_split(p, batch);
+    if (s <= 1) return 0;
+    return (size_t)s * p.output_channels * ((size_t)batch * p.output_h * p.output_w) * sizeof(float);
+}
+
+// finishes a split-K convolution: out[img][m][rem] = act(sum_s partial[s][m][n] + bias[m])
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
+                                                                 const float* __restrict__ bias, int K, int Ntot, int OHW, int S,
+                                                                 int has_bias, int relu)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= Ntot) return;
+    const size_t stride = (size_t)K * Ntot;
+    const float* src = partial + (size_t)m * Ntot + n;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += src[(size_t)s * stride];
+    if (has_bias) v += bias[m];
+    if (relu) v = fmaxf(v, 0.f);
+    const int img = n / OHW, rem = n - img * OHW;
+    out[((size_t)img * K + m) * OHW + rem] = v;
 }
 
 // K7: Wt[q][Kp] = W[k][q], zero padded (the GPU analogue of packed_sgemm_init, avx/sgemm.cpp:312-346).
@@ -215,12 +285,14 @@ static void launch(const ConvGemmParams& g0, hipStream_t s)
     ConvGemmParams g = g0;
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = ceil_div(g.Ntot, Shape::BN);
-    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s, g);
+    g.batches = g.split_k;
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.batches * g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
+                       g);
 }
 
 // force_no_act: the NAIVE algo ignores activation (avx/booster.cpp:41-61).
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
-                  bool force_no_act, hipStream_t s)
+                  float* buffer, bool force_no_act, hipStream_t s)
 {
     if (p.group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
     if (batch < 1) return fail(FHIP_E_BADARG, "batch < 1");
@@ -254,7 +326,10 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.Ntot = (int)ntot;
     g.has_bias = p.bias_term != 0;
     g.relu = (p.activation == FHIP_ACT_RELU) && !force_no_act;
-    g.k_tiles = kdp / kConvKTile;
+    g.split_k = igemm_split(p, batch);
+    if (g.split_k > 1 && !buffer) return fail(FHIP_E_BADARG, "this geometry runs split-K and needs the scratch buffer GetBufferSize asked for");
+    g.partial = buffer;
+    g.k_tiles = kdp / kConvKTile / g.split_k;
     g.m_tiles = 0;
 
     const bool one = g.KH == 1 && g.KW == 1 && p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;
@@ -275,6 +350,12 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
         else launch<ConvShapeBig, 0>(g, s);
     }
     FHIP_CHECK_HIP(hipGetLastError());
+    if (g.split_k > 1)
+    {
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot, 256), g.K), dim3(256), 0, s, out, g.partial, bias, g.K, g.Ntot,
+                           g.OHW, g.split_k, g.has_bias, g.relu);
+        FHIP_CHECK_HIP(hipGetLastError());
+    }
     return FHIP_OK;
 }
 

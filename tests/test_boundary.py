@@ -115,7 +115,12 @@ def test_buffer_sizes_are_pure_and_scale_with_batch(lib):
         assert ref_pk * 4 == pk1
         assert ref_buf >= 64 * 100 * (64 + 128)
     b.ForceSelectAlgo(IM2COL)
-    assert b.GetBufferSize(p8)[0] == 0  # the column matrix is never materialised
+    big = _param(conv_geom(64, 256, 56, 1, 1, 0), 8)
+    assert b.GetBufferSize(big)[0] == 0  # the column matrix is never materialised
+    # under-filled grids run split-K and ask for S * K * N*Ho*Wo partial sums (ResNet-50 res5 3x3 @7x7, batch 64)
+    small = _param(conv_geom(512, 512, 7, 3, 1, 1), 64)
+    sk = b.GetBufferSize(small)[0]
+    assert sk > 0 and sk % (512 * 64 * 49 * 4) == 0 and sk // (512 * 64 * 49 * 4) in (2, 3, 4, 6, 8)
     d = _param(conv_geom(32, 32, 28, 3, 1, 1, group=32), 4)
     b.SelectAlgo(d)
     assert b.algo == DEPTHWISE and b.GetBufferSize(d) == (0, 32 * 9 * 4)

@@ -24,7 +24,8 @@ namespace fhip
 struct DwParams
 {
     const float* in;
-    const float* w;
+    const float* w;   // dense [C][kh*kw]
+    const float* w12; // 3x3 only: [C][12] (9 taps + 3 zeros), 16-byte aligned rows
     const float* bias;
     float* out;
     int C, H, W, OH, OW, KH, KW, SH, SW, PL, PT;
@@ -192,8 +193,13 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
     constexpr int SPAN = (VX - 1) * S + 3; // input columns of the patch: xb-1 .. xb+SPAN-2
     constexpr int NV = (SPAN - 2 + VX - 1) / VX; // aligned centre vectors covering xb .. xb+SPAN-3
     const int HW = q.H * q.W, OHW = q.OH * q.OW;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+    const int lane = threadIdx.x & 63;
+    // every lane of a wave runs the same number of iterations (the shuffles below need their neighbours): the
+    // host rounds `total` work items up to whole waves and the tail lanes clamp to the last item without storing
+    for (long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x; idx0 - lane < total; idx0 += (long long)gridDim.x * 256)
     {
+        const bool live = idx0 < total;
+        const long long idx = live ? idx0 : total - 1;
         const int xq = (int)(idx % xvecs);
         const long long t = idx / xvecs;
         const int yb = (int)(t % yblocks);
@@ -211,7 +217,6 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
             const int y = oy0 * S - q.PT + r;
             rok[r] = (unsigned)y < (unsigned)q.H;
             const float* row = ip + (size_t)(rok[r] ? y : 0) * q.W;
-            x[r][0] = row[max(xb - 1, 0)];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
             {
@@ -224,11 +229,36 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
                     for (int e = 0; e < VX; ++e) x[r][1 + v * VX + e] = 0.f;
                 }
             }
-            x[r][NV * VX + 1] = row[min(xb + NV * VX, q.W - 1)];
+            // halo taps: the left one is the neighbouring lane's last centre element, the right one its first (lanes
+            // run along x inside a row block) -- a cross-lane move instead of two more VMEM instructions per row
+            // (the CU's address pipe, not HBM, was the limit: 22 -> 10 VMEM instructions per 16 outputs).  Only the
+            // wave's first / last lane has no neighbour and loads for real.
+            // Valid only when the neighbours' centres are contiguous with ours (NV == S; not for VX = 1 at stride 2).
+            float lft, rgt;
+            if (NV == S)
+            {
+                lft = __shfl_up(x[r][NV * VX], 1);
+                rgt = __shfl_down(x[r][1], 1);
+                if (lane == 0) lft = row[max(xb - 1, 0)];
+                if (lane == 63) rgt = row[min(xb + NV * VX, q.W - 1)];
+            }
+            else
+            {
+                lft = row[max(xb - 1, 0)];
+                rgt = row[min(xb + NV * VX, q.W - 1)];
+            }
+            x[r][0] = lft;
+            x[r][NV * VX + 1] = rgt;
         }
-        float w[9];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) w[e] = q.w[c * 9 + e];
+        // taps from the 12-float-per-channel copy Init appended to the packed weights: 3 VMEM instructions, not 9
+        float w[12];
+        {
+            const float4* w4 = reinterpret_cast<const float4*>(q.w12 + (size_t)c * 12);
+            const float4 a = w4[0], bq = w4[1], cq = w4[2];
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            w[4] = bq.x; w[5] = bq.y; w[6] = bq.z; w[7] = bq.w;
+            w[8] = cq.x; w[9] = cq.y; w[10] = cq.z; w[11] = cq.w;
+        }
         const float b = q.has_bias ? q.bias[c] : 0.f;
         const bool lok = xb > 0;
         const bool rrok = xb + NV * VX < q.W;
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
                         acc[e] += v * w[m * 3 + n];
                     }
             }
-            if (oy0 + j < q.OH)
+            if (live && oy0 + j < q.OH)
             {
                 float o[VX];
 #pragma unroll
@@ -360,6 +390,36 @@ __global__ __launch_bounds__(256) void depthwise_generic_kernel(const DwParams q
     }
 }
 
+// packed depthwise weights: the dense copy, then (3x3 kernels) a 12-floats-per-channel copy for 16-byte tap loads
+size_t depthwise_packed_floats(const fhip_conv_param& p, size_t* w12_offset)
+{
+    const size_t dense = round_up_sz((size_t)p.group * p.kernel_h * p.kernel_w, 4);
+    if (w12_offset) *w12_offset = dense;
+    return dense + ((p.kernel_h == 3 && p.kernel_w == 3) ? (size_t)p.group * 12 : 0);
+}
+
+__global__ __launch_bounds__(256) void depthwise_pack12_kernel(float* __restrict__ w12, const float* __restrict__ w, int C)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * 12) return;
+    const int c = i / 12, e = i - c * 12;
+    w12[i] = e < 9 ? w[c * 9 + e] : 0.f;
+}
+
+int depthwise_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s)
+{
+    StageTimer tm(FHIP_STAGE_INIT, s);
+    const size_t n = (size_t)p.group * p.kernel_h * p.kernel_w;
+    FHIP_CHECK_HIP(hipMemcpyAsync(packed, kernel, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    size_t off = 0;
+    if (depthwise_packed_floats(p, &off) > off)
+    {
+        hipLaunchKernelGGL(depthwise_pack12_kernel, dim3(ceil_div(p.group * 12, 256)), dim3(256), 0, s, packed + off, kernel, p.group);
+        FHIP_CHECK_HIP(hipGetLastError());
+    }
+    return FHIP_OK;
+}
+
 int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* kernel, const float* bias,
                       hipStream_t s)
 {
@@ -369,6 +429,11 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     DwParams q;
     q.in = in;
     q.w = kernel;
+    {
+        size_t off = 0;
+        depthwise_packed_floats(p, &off);
+        q.w12 = kernel + off;
+    }
     q.bias = bias;
     q.out = out;
     q.C = p.input_channels;
@@ -405,7 +470,12 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     if (k3 && dw_path == 0)
     {
         const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
-        const int R = q.SH == 1 ? 4 : 2;
+        // rows per lane: 7 divides every MobileNet plane height (112 ... 7) and re-reads 9/7 input rows instead of 6/4
+        static const int r_env = [] {
+            const char* e = getenv("FHIP_DW_R");
+            return e ? atoi(e) : 0;
+        }();
+        const int R = q.SH == 1 ? (r_env == 7 ? 7 : 4) : 2; // measured: R = 7 is 3-8 % slower than 4 except at 28x28
         const int yblocks = ceil_div(q.OH, R), xvecs = q.OW / vx;
         const long long total = planes * yblocks * xvecs;
         const int grid = (int)min((long long)256 * 32, (total + 255) / 256);
@@ -413,9 +483,18 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     hipLaunchKernelGGL((depthwise3x3_direct_kernel<S_, VX_, R_>), dim3(grid), dim3(256), 0, s, q, yblocks, xvecs, total)
         if (q.SH == 1)
         {
-            if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
-            else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
-            else FHIP_DW_LAUNCH(1, 1, 4);
+            if (R == 7)
+            {
+                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 7);
+                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 7);
+                else FHIP_DW_LAUNCH(1, 1, 7);
+            }
+            else
+            {
+                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
+                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
+                else FHIP_DW_LAUNCH(1, 1, 4);
+            }
         }
         else
         {

@@ -107,9 +107,12 @@ struct WinoXformParams
 __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __restrict__ V, const float* __restrict__ in,
                                                                   const WinoXformParams q)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (p >= q.P) return;
+    // flattened (channel, column) index, column fastest: no partially filled blocks when P is small (14x14 images
+    // at batch 32 have P = 288: a per-channel grid would run its second block of 256 lanes with 32 of them)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)q.C * q.P) return;
+    const int c = (int)(idx / q.P);
+    const int p = (int)(idx - (long long)c * q.P);
     const int n = p / q.T, t = p - n * q.T;
     const int ty = t / q.TX, tx = t - ty * q.TX;
     const int y0 = ty * 6 - q.PT, x0 = tx * 6 - q.PL;
@@ -392,7 +395,9 @@ int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, cons
     if (rc) return rc;
     const WinoXformParams q = xform_params(p, batch, pl);
     StageTimer tm(FHIP_STAGE_WINO_INPUT, s);
-    dim3 grid(ceil_div(q.P, 256), q.C);
+    const long long work = (long long)q.C * q.P;
+    if ((work + 255) / 256 > 0x7fffffffLL) return fail(FHIP_E_BADARG, "input transform grid too large");
+    dim3 grid((unsigned)((work + 255) / 256));
     hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;

@@ -107,7 +107,8 @@ def test_buffer_sizes_are_pure_and_scale_with_batch(lib):
     assert pk1 == pk8 == 64 * 64 * 128 * 4     # U[64][C][K] fp32 (the reference packs the same 64*C*K floats, avx/booster.cpp:194)
     pl1, pl8 = booster.winograd_plan(p1), booster.winograd_plan(p8)
     assert pl1.tiles_x == pl1.tiles_y == 10 and pl1.tiles_per_image == 100 and pl8.columns == 800
-    assert buf8 == pl8.v_bytes + pl8.m_bytes and buf8 > 7 * buf1 * 0.8
+    # one V / M slice per pipelined sub-batch: the sum of the slices, never less than the single-slice plan minus padding
+    assert pl8.v_bytes + pl8.m_bytes <= buf8 <= (pl8.v_bytes + pl8.m_bytes) * 1.1 and buf8 > 7 * buf1 * 0.8
     assert pl8.columns_padded % 128 == 0 and pl8.v_offset_bytes == 0 and pl8.m_offset_bytes == pl8.v_bytes
     # the reference's own scratch for ONE image (float counts, avx/booster.cpp:178-197) has the same V/M terms: 64*T*C + 64*T*K
     if oracle.have_ref():
@@ -123,7 +124,7 @@ def test_buffer_sizes_are_pure_and_scale_with_batch(lib):
     assert sk > 0 and sk % (512 * 64 * 49 * 4) == 0 and sk // (512 * 64 * 49 * 4) in (2, 3, 4, 6, 8)
     d = _param(conv_geom(32, 32, 28, 3, 1, 1, group=32), 4)
     b.SelectAlgo(d)
-    assert b.algo == DEPTHWISE and b.GetBufferSize(d) == (0, 32 * 9 * 4)
+    assert b.algo == DEPTHWISE and b.GetBufferSize(d) == (0, (32 * 9 + 32 * 12) * 4)  # dense copy + 12-stride copy for 16-byte tap loads
 
 
 def test_no_device_is_reported_not_faked(lib):

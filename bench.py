@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--net", default="vgg16", choices=list(DEFAULT_BATCH))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay per step")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: all cores, max 64)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
     return ap.parse_args()
@@ -186,9 +187,25 @@ def main():
     scratch = torch.empty(max(max_scratch // 4, 1), dtype=torch.float32, device=dev)  # one shared arena (mempool.cpp:88-92)
     out = torch.empty(max_out, dtype=torch.float32, device=dev)
 
-    def step():
+    def eager_step():
         for _, prm, lyr, x in built:
             lyr.booster.Forward(prm, out, x, lyr.packed, scratch, lyr.bias)
+
+    # One step = one hipGraph replay: the layer launches of a step are captured once (HIP graphs instead of a tracing
+    # compiler); Forward never allocates and has no host-side state, so it is capturable as is.  --no-graph times the
+    # eager launch loop instead.
+    step, graph_used = eager_step, False
+    if not a.no_graph:
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                eager_step()
+            step, graph_used = cg.replay, True
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print(f"bench: hipGraph capture unavailable ({e!r}); timing eager launches", file=sys.stderr)
+            step, graph_used = eager_step, False
 
     def barrier():
         if world > 1:
@@ -282,7 +299,8 @@ def main():
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.net} conv layers ({len(layers)}), batch {batch} per GPU, 224x224x3, bias+ReLU fused, fp32",
-                       "net": a.net, "per_gpu_batch": batch, "global_batch": batch * n_gpus, "parallelism": f"batch-shard x{n_gpus}"},
+                       "net": a.net, "per_gpu_batch": batch, "global_batch": batch * n_gpus, "parallelism": f"batch-shard x{n_gpus}",
+                       "launch": "hipGraph replay per step" if graph_used else "eager launches"},
             "conv_gflops_per_s_direct": round(flops_direct_total * n_gpus / (ms_per_step * 1e6), 1) if rank == 0 else None,
             "conv_direct_frac_of_mfma_peak": round(flops_direct_total / (ms_per_step * 1e6) / 1e3 / PEAK_MFMA_F32_TFLOPS, 4),
             "stage_ms_per_step": stage_ms,

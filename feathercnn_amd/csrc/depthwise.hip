@@ -4,16 +4,17 @@
 // global-kernel case :30-54).  Same arithmetic -- per-channel 2-D correlation, taps accumulated in (m, n) order
 // in fp32, + bias[c], ReLU, floor output dims -- but no padded copy of the input: padding is a bounds check.
 //
-// This is an HBM-bound kernel (9 FMA per 8 bytes moved): the whole job is to move each input and output
-// element once, in 16-byte coalesced accesses.  Fast path (3x3, stride 1 or 2, the MobileNet shapes):
-//   * the NCHW tensor is a flat run of (n,c) planes, so a block takes a CHUNK of consecutive whole planes
-//     (as many as fit the LDS budget) and copies it global->LDS with straight float4 loads -- perfectly
-//     coalesced, no halo re-reads, no per-row address math;
-//   * every lane then produces 4 consecutive outputs of one row from three 16-byte LDS reads per input row
-//     (conflict-free ds_read_b128; the left/right halo taps come from the neighbouring aligned quads) and
-//     writes them with one float4 store -- output planes of a chunk are contiguous too.
-// Everything else (other kernel sizes, strides, widths not divisible by 4, planes larger than LDS, the
-// global-kernel case) goes through a generic one-output-per-lane kernel.
+// This is an HBM-bound kernel (9 FMA per 8 bytes moved): the whole job is to move each input and output element once.
+// Three forms live here, chosen by shape (measurements in DESIGN.md 3.3):
+//   * depthwise3x3_direct_kernel  -- 3x3, stride 1/2, pad_left 1 (the MobileNet shapes).  NO LDS: every lane produces
+//     a VX-wide x R-high output patch straight from global memory with aligned vector loads, takes its two halo taps
+//     per row from the neighbouring lanes (cross-lane moves, not loads), and stores R vectors.  52-57 % of HBM peak.
+//   * depthwise3x3_lds_kernel / depthwise_lds_scalar_kernel -- the LDS-staged design BASELINE.json asks for: a block
+//     copies a chunk of whole planes global->LDS with coalesced 16-byte loads and computes from LDS.  Measured at
+//     24 % of peak on MobileNet-V1 (load / compute / store phases serialise inside a block at 2 blocks per CU);
+//     kept selectable (FHIP_DW_PATH=lds) and used for 3x3 shapes the direct form does not cover.
+//   * depthwise_generic_kernel -- any kernel size / stride / plane size, one output per lane (incl. the reference's
+//     global-kernel special case).
 #include <stdlib.h>
 
 #include "common.h"

@@ -136,10 +136,29 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- prologue: k-tile 0 -> LDS buffer 0, k-tile 1 -> registers
+    // ---- prologue: k-tile 0 -> LDS buffer 0, k-tile 1 -> registers.  Both tiles' loads are issued back to back
+    // (a second register set for a moment), so the block pays ONE global round trip before its first MFMA, not two.
     fetch(0);
-    stash(0);
-    if (k_tiles > 1) fetch(1);
+    if (k_tiles > 1)
+    {
+        float4 qa[Shape::A_PASSES], qb[Shape::B_PASSES];
+        unsigned qok[Shape::B_PASSES];
+#pragma unroll
+        for (int i = 0; i < Shape::A_PASSES; ++i) qa[i] = aload.load(prm, BK + a_r + i * Shape::A_ROWS_PER_PASS);
+#pragma unroll
+        for (int i = 0; i < Shape::B_PASSES; ++i) qb[i] = bload.load(prm, BK + b_r + i * Shape::B_ROWS_PER_PASS, qok[i]);
+        stash(0); // waits for tile 0's loads only (vmcnt counts in order)
+#pragma unroll
+        for (int i = 0; i < Shape::A_PASSES; ++i) pa[i] = qa[i];
+#pragma unroll
+        for (int i = 0; i < Shape::B_PASSES; ++i)
+        {
+            pb[i] = qb[i];
+            pok[i] = qok[i];
+        }
+    }
+    else
+        stash(0);
     __syncthreads();
 
     const int a_off = half * BM + wm * Shape::WTM + l31;

@@ -75,3 +75,14 @@ def test_port_sweep_vs_fp64(port):
               conv_geom(48, 24, 13, 1, 1, 0), conv_geom(3, 8, 33, 7, 2, 3), conv_geom(12, 12, 21, 3, 2, 1, group=12)]:
         x, w, b = synth(g, 2, seed=7)
         assert nerr(port.forward(g, x, w, b), port.direct_f64(g, x, w, b)) <= 5e-5
+
+
+def test_port_covers_shapes_the_reference_crashes_on(port):
+    """Reference quirk found while pinning: the compiled AVX Winograd path segfaults (heap overrun) on ragged tile grids
+    when input_channels % 8 == 4 -- e.g. 20->36 @19x19, 4->4 @19x19, 20->32 @25x25 -- while 16/24 channels or 18/20-pixel
+    inputs are fine.  Parity tests therefore never send such a shape to oracle/_ref; the restatement has no such limit and is
+    checked against the fp64 direct convolution here."""
+    for g in [conv_geom(20, 36, 19, 3, 1, 1), conv_geom(4, 4, 19, 3, 1, 1), conv_geom(20, 32, 25, 3, 1, 1)]:
+        assert port.select_algo(g) == oracle.WINOGRADF63
+        x, w, b = synth(g, 2, seed=4)
+        assert nerr(port.forward(g, x, w, b), port.direct_f64(g, x, w, b)) <= 5e-5

@@ -1,0 +1,253 @@
+// layers.hip -- SURVEY.md 8(f) rank 1: the layers BETWEEN the convolutions on the device, so a whole forward pass stays
+// in HBM.  All of them are HBM-bound elementwise / window kernels; each follows the reference layer it replaces
+// (paths relative to /root/reference/src):
+//   relu            layers/relu_layer.h:29-41
+//   add (+relu)     layers/eltwise_layer.h:69-80 -> booster::add_relu<fuse_relu>, booster/avx/generic_kernels.cpp:138
+//   affine (+relu)  layers/batchnorm_layer.h:43-75 (folded alpha/beta), booster::batchnorm<bias,scale,relu>
+//                   generic_kernels.cpp:237-279, layers/scale_layer.h + booster::scale<bias> generic_kernels.cpp:203-233
+//   pooling         layers/pooling_layer.h:37-88 (max / average / global; NB the window origin subtracts BOTH pads,
+//                   :56,:67, the divisor is the number of in-range taps, output dims use ceil, :129-130)
+//   softmax         layers/softmax_layer.h:33-53 (over the whole C*H*W of an image)
+// InnerProduct needs no kernel of its own: it is a 1x1 convolution over a 1x1 image with C*H*W input channels and runs
+// through the implicit-GEMM path (split-K takes care of the tiny N = batch).
+#include <float.h>
+
+#include "common.h"
+
+namespace fhip
+{
+
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n4, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = fmaxf(x[i], 0.f);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
+                                                 size_t n4, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        float4 r = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+        if (RELU)
+        {
+            r.x = fmaxf(r.x, 0.f);
+            r.y = fmaxf(r.y, 0.f);
+            r.z = fmaxf(r.z, 0.f);
+            r.w = fmaxf(r.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    {
+        const float r = a[i] + b[i];
+        y[i] = RELU ? fmaxf(r, 0.f) : r;
+    }
+}
+
+// y[n][c][:] = x[n][c][:] * mul[c] + add[c]  (+ ReLU); one (n, c) plane per blockIdx.x
+template <bool RELU>
+__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ mul,
+                                                    const float* __restrict__ add, int C, int HW)
+{
+    const int plane = blockIdx.x;
+    const int c = plane % C;
+    const float m = mul[c], a = add ? add[c] : 0.f;
+    const float* xp = x + (size_t)plane * HW;
+    float* yp = y + (size_t)plane * HW;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < HW; i += gridDim.y * 256)
+    {
+        const float v = xp[i] * m + a;
+        yp[i] = RELU ? fmaxf(v, 0.f) : v;
+    }
+}
+
+struct PoolParams
+{
+    int planes, H, W, OH, OW, KH, KW, SH, SW;
+    int off_y, off_x; // window origin offset = pad_top + pad_bottom / pad_left + pad_right (reference quirk)
+    int average;
+};
+
+__global__ __launch_bounds__(256) void pooling_kernel(float* __restrict__ y, const float* __restrict__ x, const PoolParams q, long long total)
+{
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+    {
+        const int ox = (int)(idx % q.OW);
+        const long long t = idx / q.OW;
+        const int oy = (int)(t % q.OH);
+        const long long plane = t / q.OH;
+        const float* xp = x + plane * q.H * q.W;
+        const int y0 = oy * q.SH - q.off_y, x0 = ox * q.SW - q.off_x;
+        const int ya = max(y0, 0), yb = min(y0 + q.KH, q.H);
+        const int xa = max(x0, 0), xb = min(x0 + q.KW, q.W);
+        float total_v = q.average ? 0.f : -FLT_MAX;
+        int counter = 0;
+        for (int yy = ya; yy < yb; ++yy)
+            for (int xx = xa; xx < xb; ++xx)
+            {
+                const float v = xp[yy * q.W + xx];
+                if (q.average)
+                {
+                    total_v += v;
+                    ++counter;
+                }
+                else
+                    total_v = total_v > v ? total_v : v;
+            }
+        y[idx] = q.average ? total_v / counter : total_v; // empty window: 0/0 = NaN exactly like the reference
+    }
+}
+
+// one block per image: max, exp-sum, normalise over `cols` values
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ y, const float* __restrict__ x, int cols)
+{
+    __shared__ float red[256];
+    const float* xp = x + (size_t)blockIdx.x * cols;
+    float* yp = y + (size_t)blockIdx.x * cols;
+    float m = -FLT_MAX;
+    for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, xp[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1)
+    {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256)
+    {
+        const float e = expf(xp[i] - m);
+        yp[i] = e;
+        sum += e;
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1)
+    {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    sum = red[0];
+    for (int i = threadIdx.x; i < cols; i += 256) yp[i] = yp[i] / sum;
+}
+
+static int ew_grid(size_t n4)
+{
+    const size_t blocks = (n4 + 255) / 256;
+    return (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 16));
+}
+
+} // namespace fhip
+
+using namespace fhip;
+
+extern "C"
+{
+
+int fhip_relu(float* y, const float* x, size_t count, void* stream)
+{
+    if (!y || !x) return fail(FHIP_E_BADARG, "null pointer");
+    if (count == 0) return FHIP_OK;
+    const bool vec = (((uintptr_t)y | (uintptr_t)x) & 15) == 0;
+    const size_t n4 = vec ? count / 4 : 0;
+    hipLaunchKernelGGL(relu_kernel, dim3(ew_grid(std::max<size_t>(n4, count / 64))), dim3(256), 0, (hipStream_t)stream, y, x, n4, count);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int fhip_add(float* y, const float* a, const float* b, size_t count, int relu, void* stream)
+{
+    if (!y || !a || !b) return fail(FHIP_E_BADARG, "null pointer");
+    if (count == 0) return FHIP_OK;
+    const bool vec = (((uintptr_t)y | (uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const size_t n4 = vec ? count / 4 : 0;
+    const dim3 grid(ew_grid(std::max<size_t>(n4, count / 64)));
+    if (relu)
+        hipLaunchKernelGGL(add_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, a, b, n4, count);
+    else
+        hipLaunchKernelGGL(add_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, a, b, n4, count);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int fhip_affine(float* y, const float* x, const float* mul, const float* add, int batch, int channels, int hw, int relu, void* stream)
+{
+    if (!y || !x || !mul || batch < 1 || channels < 1 || hw < 1) return fail(FHIP_E_BADARG, "bad argument");
+    const long long planes = (long long)batch * channels;
+    if (planes > 0x7fffffffLL) return fail(FHIP_E_BADARG, "batch * channels too large");
+    const dim3 grid((unsigned)planes, std::max(1, std::min(ceil_div(hw, 1024), 64)));
+    if (relu)
+        hipLaunchKernelGGL(affine_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, x, mul, add, channels, hw);
+    else
+        hipLaunchKernelGGL(affine_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, x, mul, add, channels, hw);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int fhip_pooling_output_dim(const fhip_pool_param* p, int* out_h, int* out_w)
+{
+    if (!p || !out_h || !out_w) return fail(FHIP_E_BADARG, "null argument");
+    if (p->global_pooling)
+    {
+        *out_h = 1;
+        *out_w = 1;
+        return FHIP_OK;
+    }
+    if (p->stride_h < 1 || p->stride_w < 1) return fail(FHIP_E_BADARG, "stride < 1");
+    // ceil, layers/pooling_layer.h:129-130
+    *out_h = (int)ceilf((float)(p->input_h + p->pad_top + p->pad_bottom - p->kernel_h) / p->stride_h) + 1;
+    *out_w = (int)ceilf((float)(p->input_w + p->pad_left + p->pad_right - p->kernel_w) / p->stride_w) + 1;
+    return FHIP_OK;
+}
+
+int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const float* x, void* stream)
+{
+    if (!p || !y || !x || batch < 1 || p->channels < 1) return fail(FHIP_E_BADARG, "bad argument");
+    PoolParams q;
+    int oh = 0, ow = 0;
+    int rc = fhip_pooling_output_dim(p, &oh, &ow);
+    if (rc) return rc;
+    if (oh < 1 || ow < 1) return fail(FHIP_E_BADARG, "empty pooling output");
+    q.planes = batch * p->channels;
+    q.H = p->input_h;
+    q.W = p->input_w;
+    q.OH = oh;
+    q.OW = ow;
+    q.KH = p->global_pooling ? p->input_h : p->kernel_h;
+    q.KW = p->global_pooling ? p->input_w : p->kernel_w;
+    q.SH = p->global_pooling ? 1 : p->stride_h;
+    q.SW = p->global_pooling ? 1 : p->stride_w;
+    q.off_y = p->pad_top + p->pad_bottom;
+    q.off_x = p->pad_left + p->pad_right;
+    q.average = p->pooling_type != 0;
+    const long long total = (long long)q.planes * oh * ow;
+    const int grid = (int)std::min<long long>(256 * 16, (total + 255) / 256);
+    hipLaunchKernelGGL(pooling_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, q, total);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+int fhip_softmax(float* y, const float* x, int batch, int count_per_image, void* stream)
+{
+    if (!y || !x || batch < 1 || count_per_image < 1) return fail(FHIP_E_BADARG, "bad argument");
+    hipLaunchKernelGGL(softmax_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, y, x, count_per_image);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+} // extern "C"

@@ -56,7 +56,7 @@ WINO = [
     (conv_geom(128, 256, 14, 3, 1, 1), 4),
     (conv_geom(512, 512, 14, 3, 1, 1), 2),         # VGG conv5
     (conv_geom(64, 64, 224, 3, 1, 1), 1),          # VGG conv1_2 (1444 tiles)
-    (conv_geom(20, 36, 12, 3, 1, 0), 2),           # no padding, C % 16 != 0
+    (conv_geom(24, 36, 12, 3, 1, 0), 2),           # no padding, C % 16 != 0 (not 20: the reference crashes on C % 8 == 4 with ragged tiles)
     (conv_geom(12, 8, 20, 3, 1, 2), 2),            # pad 2 (wider than the kernel needs)
 ]
 
@@ -391,3 +391,15 @@ def test_measurement_switch_paths_stay_correct(env, cuda, tmp_path):
     e.update(env)
     out = subprocess.run([sys.executable, str(script), root], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("g,batch", [(conv_geom(20, 36, 19, 3, 1, 1), 3), (conv_geom(4, 4, 19, 3, 1, 1), 2), (conv_geom(20, 32, 25, 3, 1, 1), 2)],
+                         ids=["20x36@19", "4x4@19", "20x32@25"])
+def test_winograd_shapes_the_reference_crashes_on(g, batch, cuda, port):
+    """input_channels % 8 == 4 with a ragged tile grid segfaults the compiled reference (tests/test_oracle.py); the HIP path is
+    checked against the pinned C restatement and the fp64 direct convolution instead."""
+    x, w, b = synth(g, batch, seed=8)
+    y, used = run_gpu(g, x, w, b, cuda)
+    assert used == oracle.WINOGRADF63
+    assert nerr(y, port.forward(g, x, w, b)) <= TOL
+    assert nerr(y, port.direct_f64(g, x, w, b)) <= TOL

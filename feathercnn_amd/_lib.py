@@ -24,7 +24,17 @@ class fhip_winograd_plan(ctypes.Structure):
                 ("m_offset_bytes", ctypes.c_size_t), ("m_bytes", ctypes.c_size_t), ("u_bytes", ctypes.c_size_t)]
 
 
+class fhip_pool_param(ctypes.Structure):
+    """fhip_pool_param (feather_net.h), the fields PoolingLayer::LoadParam reads (reference pooling_layer.h:90-107)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "channels", "input_h", "input_w", "kernel_h", "kernel_w", "stride_h", "stride_w", "pad_left", "pad_right",
+        "pad_top", "pad_bottom", "pooling_type", "global_pooling")]
+
+
 _P = ctypes.POINTER(fhip_conv_param)
+_Q = ctypes.POINTER(fhip_pool_param)
+_PI = ctypes.POINTER(ctypes.c_int)
+_SZ = ctypes.c_size_t
 _V = ctypes.c_void_p
 _I = ctypes.c_int
 
@@ -46,6 +56,31 @@ SIGNATURES = {
     "fhip_last_error": (ctypes.c_char_p, []),
     "fhip_version": (ctypes.c_char_p, []),
     "fhip_device_info": (_I, [ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    # include/feather_hip/feather_net.h -- layers between the convolutions
+    "fhip_relu": (_I, [_V, _V, _SZ, _V]),
+    "fhip_add": (_I, [_V, _V, _V, _SZ, _I, _V]),
+    "fhip_affine": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V]),
+    "fhip_pooling_output_dim": (_I, [_Q, _PI, _PI]),
+    "fhip_pooling": (_I, [_Q, _I, _V, _V, _V]),
+    "fhip_softmax": (_I, [_V, _V, _I, _I, _V]),
+    # include/feather_hip/feather_net.h -- feather::Net on device blobs
+    "fhip_net_create": (_I, [ctypes.POINTER(_V)]),
+    "fhip_net_destroy": (_I, [_V]),
+    "fhip_net_set_stream": (_I, [_V, _V]),
+    "fhip_net_set_fusion": (_I, [_V, _I]),
+    "fhip_net_set_graph": (_I, [_V, _I]),
+    "fhip_net_load_param": (_I, [_V, ctypes.c_char_p]),
+    "fhip_net_load_param_mem": (_I, [_V, ctypes.c_char_p, _SZ]),
+    "fhip_net_load_weights": (_I, [_V, ctypes.c_char_p]),
+    "fhip_net_load_weights_mem": (_I, [_V, _V, _SZ]),
+    "fhip_net_feed_input": (_I, [_V, ctypes.c_char_p, _I, _I, _I, _I, _V, _I]),
+    "fhip_net_forward": (_I, [_V]),
+    "fhip_net_extract": (_I, [_V, ctypes.c_char_p, ctypes.POINTER(_V), _PI, _PI, _PI, _PI]),
+    "fhip_net_extract_host": (_I, [_V, ctypes.c_char_p, _V, _SZ]),
+    "fhip_net_layer_count": (_I, [_V]),
+    "fhip_net_layer_info": (_I, [_V, _I, ctypes.c_char_p, ctypes.c_char_p, _I, _PI]),
+    "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
+    "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }
 
 

@@ -12,7 +12,10 @@
 // through the implicit-GEMM path (split-K takes care of the tiny N = batch).
 #include <float.h>
 
+#include <algorithm>
+
 #include "common.h"
+#include "feather_hip/feather_net.h"
 
 namespace fhip
 {

@@ -1,0 +1,104 @@
+/* feather_net.h -- C-ABI of the layers between the convolutions and of the feather::Net-compatible
+ * runtime on device blobs (the callers and data formats either side of the
+ * ConvBooster hot path).  Same conventions as feather_hip.h: plain C, DEVICE pointers (fp32 NCHW dense),
+ * `stream` is a hipStream_t as void*, every call returns 0 or a negative fhip_error.
+ *
+ * Paths cited are relative to /root/reference/src.
+ */
+#ifndef FEATHER_NET_H_
+#define FEATHER_NET_H_
+
+#include "feather_hip/feather_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- layer kernels ---------------------------------------------------------------------------------- */
+
+/* ReluLayer::Forward, layers/relu_layer.h:29-41: y = x > 0 ? x : 0 over `count` floats. */
+FHIP_API int fhip_relu(float* y, const float* x, size_t count, void* stream);
+
+/* EltwiseLayer::Forward (SUM only) -> booster::add_relu<fuse_relu>, layers/eltwise_layer.h:69-80,
+ * booster/avx/generic_kernels.cpp:138: y = a + b, then max(0, .) when relu != 0. */
+FHIP_API int fhip_add(float* y, const float* a, const float* b, size_t count, int relu, void* stream);
+
+/* booster::scale<bias> (generic_kernels.cpp:203-233) and booster::batchnorm<bias,scale,relu>
+ * (generic_kernels.cpp:237-279) are both per-channel affine maps: y[n][c][i] = x[n][c][i]*mul[c] + add[c],
+ * optionally followed by ReLU.  mul/add are device vectors of `channels` floats; add may be NULL. */
+FHIP_API int fhip_affine(float* y, const float* x, const float* mul, const float* add, int batch, int channels, int hw,
+                         int relu, void* stream);
+
+/* PoolingLayer, layers/pooling_layer.h:90-131 (fields as its LoadParam reads them). */
+typedef struct fhip_pool_param
+{
+    int channels, input_h, input_w;
+    int kernel_h, kernel_w;
+    int stride_h, stride_w;
+    int pad_left, pad_right, pad_top, pad_bottom;
+    int pooling_type;   /* 0 = max, anything else = average (pooling_layer.h:75) */
+    int global_pooling; /* kernel = whole image, output 1x1 (pooling_layer.h:116-123) */
+} fhip_pool_param;
+
+/* PoolingLayer::Reshape, pooling_layer.h:116-131: ceil((in + pads - k) / stride) + 1, or 1x1 when global. */
+FHIP_API int fhip_pooling_output_dim(const fhip_pool_param* p, int* out_h, int* out_w);
+/* PoolingLayer::Forward, pooling_layer.h:37-88.  Reference semantics kept exactly: the window origin is
+ * j*stride - pad_top - pad_bottom (both pads, :56,:67), windows are clipped to the image, the average
+ * divides by the number of in-range taps, an empty window yields -FLT_MAX (max) or NaN (average). */
+FHIP_API int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const float* x, void* stream);
+
+/* SoftmaxLayer::Forward, layers/softmax_layer.h:33-53: max-subtracted exp / sum over all
+ * `count_per_image` values of each image. */
+FHIP_API int fhip_softmax(float* y, const float* x, int batch, int count_per_image, void* stream);
+
+/* ---- feather::Net on device blobs --------------------------------------------------------------------- */
+
+/* Opaque handle to a feather::Net (include/feather/net.h; reference net.h:30-70). */
+typedef struct fhip_net fhip_net;
+
+FHIP_API int fhip_net_create(fhip_net** net);
+FHIP_API int fhip_net_destroy(fhip_net* net);
+/* All work of this net is enqueued on `stream` (default: the NULL stream).  Set before the first Forward. */
+FHIP_API int fhip_net_set_stream(fhip_net* net, void* stream);
+/* 1 (default): run the TryFuse pass the reference declares but never calls (layer.cpp:82-101):
+ * Conv+ReLU, InnerProduct+ReLU, BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.  Set before LoadParam. */
+FHIP_API int fhip_net_set_fusion(fhip_net* net, int on);
+/* 1: after the first Forward for a shape, record the layer sequence into a hipGraph and replay it.  Capture is not
+ * allowed on the NULL stream: if no stream was set, the net creates and uses its own non-blocking stream (order device
+ * inputs produced on other streams yourself). */
+FHIP_API int fhip_net_set_graph(fhip_net* net, int on);
+
+/* Net::LoadParam, net.cpp:54-170 (ncnn text .param: magic 7767517, "layers blobs", one line per layer). */
+FHIP_API int fhip_net_load_param(fhip_net* net, const char* path);
+FHIP_API int fhip_net_load_param_mem(fhip_net* net, const char* text, size_t len);
+/* Net::LoadWeights, net.cpp:172-233 (ncnn .bin read in layer order; ncnn/modelbin.cpp:47-197). */
+FHIP_API int fhip_net_load_weights(fhip_net* net, const char* path);
+FHIP_API int fhip_net_load_weights_mem(fhip_net* net, const void* data, size_t len);
+
+/* Net::FeedInput, net.cpp:235-246, extended with a batch.  `data` holds n*c*h*w floats; `on_device` says
+ * whether it is a device pointer (copied device-to-device on the net's stream) or a host pointer. */
+FHIP_API int fhip_net_feed_input(fhip_net* net, const char* blob_name, int n, int c, int h, int w, const float* data,
+                                 int on_device);
+/* Net::Forward, net.cpp:297-334: Reshape when the input shape changed, Init once, then every layer in file
+ * order on the net's stream.  Asynchronous: returns after enqueueing. */
+FHIP_API int fhip_net_forward(fhip_net* net);
+/* Net::Extract(name, float**, n, c, h, w), net.cpp:263-279: DEVICE pointer into the net's blob + its shape.
+ * The pointer stays valid until the next Reshape. */
+FHIP_API int fhip_net_extract(fhip_net* net, const char* blob_name, float** device_ptr, int* n, int* c, int* h, int* w);
+/* Convenience: synchronise the stream and copy the blob to a host buffer of `capacity` floats. */
+FHIP_API int fhip_net_extract_host(fhip_net* net, const char* blob_name, float* host, size_t capacity);
+
+/* Introspection (after LoadParam / fusion). */
+FHIP_API int fhip_net_layer_count(fhip_net* net);
+/* type / name are copied (truncated) into caller buffers of `len` bytes; algo = fhip_conv_algo for
+ * convolutions after the first Forward, else -1. */
+FHIP_API int fhip_net_layer_info(fhip_net* net, int index, char* type, char* name, int len, int* algo);
+/* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
+FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
+/* Device bytes currently held: blobs, weights, scratch arena. */
+FHIP_API int fhip_net_memory(fhip_net* net, size_t* blob_bytes, size_t* weight_bytes, size_t* arena_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEATHER_NET_H_ */

@@ -14,7 +14,7 @@ from helpers import golden_cases
 from oracle import conv_geom
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "feather_hip", "feather_hip.h")
+HEADERS = [os.path.join(ROOT, "include", "feather_hip", h) for h in ("feather_hip.h", "feather_net.h")]
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,7 @@ def lib():
 
 
 def declared_symbols():
-    txt = open(HEADER).read()
+    txt = "".join(open(h).read() for h in HEADERS)
     return sorted(set(re.findall(r"FHIP_API\s+[\w\s\*]+?\b(fhip_\w+)\s*\(", txt)))
 
 

@@ -1,0 +1,116 @@
+"""Whole-net path without a GPU: the two CPU checkers agree with each other and with the committed reference fixtures, the
+synthetic ncnn models are well-formed, and the product's readers (LoadParam / LoadWeights, host-only) accept them and
+reject malformed files with the reference's error codes.  No compute call is made here."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from feathercnn_amd import model_zoo
+from oracle import nerr, netcheck
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def test_port_net_matches_reference_fixtures(golden):
+    """The numpy/C restatement of every layer against blobs the REAL reference produced (tests/golden/make_net_golden.py)."""
+    p, b = golden["tiny/param"].tobytes(), golden["tiny/bin"].tobytes()
+    blobs = netcheck.PortNet(p, b).run("data", golden["tiny/x"], "prob", keep=True)
+    names = [k.split("/")[2] for k in golden.files if k.startswith("tiny/blob/")]
+    assert len(names) >= 14
+    for n in names:
+        assert blobs[n].shape == golden["tiny/blob/" + n].shape, n
+        assert nerr(blobs[n], golden["tiny/blob/" + n]) <= 1e-5, n
+
+
+def test_tiny_model_regenerates_bit_identically(golden):
+    p, b, _, _ = model_zoo.tiny_allsorts()
+    assert p == golden["tiny/param"].tobytes()
+    assert b == golden["tiny/bin"].tobytes()
+
+
+def test_port_net_squeezenet_matches_reference_fixture(golden):
+    p, b, i, o = model_zoo.squeezenet_v11()
+    assert hashlib.sha256(b).digest() == golden["squeezenet/bin_sha256"].tobytes(), "numpy RNG stream changed: regenerate fixtures"
+    x = np.random.default_rng(43).uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    blobs = netcheck.PortNet(p, b).run(i, x, o, keep=True)
+    assert nerr(blobs[o], golden["squeezenet/prob"]) <= 1e-5
+    assert nerr(blobs["fire5_concat"][:, :8], golden["squeezenet/fire5"]) <= 1e-5
+    assert abs(float(blobs[o][0].sum()) - 1.0) < 1e-5
+
+
+@pytest.mark.skipif(not netcheck.have_ref_net(), reason="oracle/_ref/libfeather_net_ref.so not built (needs /root/reference)")
+def test_reference_net_live_matches_fixture_and_port(golden):
+    p, b = golden["tiny/param"].tobytes(), golden["tiny/bin"].tobytes()
+    ref = netcheck.RefNet(p, b)
+    y = ref.run("data", golden["tiny/x"], "prob")
+    ref.close()
+    assert np.array_equal(y, golden["tiny/blob/prob"])
+    # pooling quirks: pads shift the window twice, average divides by in-range taps (pooling_layer.h:56-88)
+    g = model_zoo.GraphBuilder(3)
+    x = g.input("data", 4, 11, 9)
+    a, b2 = g.split("s", x)
+    g.layer("Pooling", "pmax", [a], ["pmax"], {0: 0, 1: 3, 2: 2, 3: 1})
+    g.layer("Pooling", "pavg", [b2], ["pavg"], {0: 1, 1: 2, 11: 3, 2: 2, 12: 1, 3: 0, 13: 1, 15: 0})
+    param, weights = g.finish()
+    img = np.random.default_rng(5).uniform(-1, 1, (1, 4, 11, 9)).astype(np.float32)
+    ref = netcheck.RefNet(param, weights)
+    port = netcheck.PortNet(param, weights)
+    for name in ("pmax", "pavg"):
+        r, q = ref.run("data", img, name), port.run("data", img, name)
+        assert r.shape == q.shape and nerr(q, r) <= 1e-6, name
+    ref.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_allsorts", "squeezenet_v1.1", "mobilenet_v1", "resnet50"])
+def test_product_readers_accept_zoo_models(name):
+    from feathercnn_amd.net import Net
+    p, b, _, _ = model_zoo.MODELS[name]()
+    layers = netcheck.parse_param(p)
+    net = Net()
+    net.LoadParam(p)
+    net.LoadWeights(b)
+    got = net.layers()
+    assert [(t, n) for t, n, _ in got] == [(t, n) for t, n, _, _, _ in layers]
+    # every weight byte is consumed, in the reference's order: the restatement reads the same stream to its end
+    assert netcheck.PortNet(p, b) is not None
+
+
+def test_product_readers_reject_malformed_models():
+    from feathercnn_amd import FeatherHipError
+    from feathercnn_amd.net import Net
+    cases = [(b"123\n1 1\nInput data 0 1 data\n", "-1"),                                           # utils.cpp:37-41
+             (b"7767517\n0 0\n", "-1"),                                                             # net.cpp:79-83
+             (b"7767517\n1 1\nFoo a 0 1 a\n", "-200"),                                              # net.cpp:108-112
+             (b"7767517\n2 2\nInput data 0 1 data\nReLU r 1 1 nope r\n", "-300"),                   # net.cpp:131-135
+             (b"7767517\n2 2\nInput data 0 1 data\nConvolution c 1 1 data c 0=4 1=3 2=2 6=108\n", "-200"),   # dilation
+             (b"7767517\n2 2\nInput data 0 1 data\nEltwise e 1 1 data e 0=0\n", "-100")]            # eltwise_layer.h:62-66
+    for text, code in cases:
+        with pytest.raises(FeatherHipError, match=f"code {code}"):
+            Net().LoadParam(text)
+    p, b, _, _ = model_zoo.tiny_allsorts()
+    net = Net()
+    net.LoadParam(p)
+    with pytest.raises(FeatherHipError, match="file too short"):
+        net.LoadWeights(b[:-8])
+    with pytest.raises(FeatherHipError):
+        Net().LoadWeights(b)  # net.cpp:193-197: param first
+    with pytest.raises(FeatherHipError, match="Cannot open"):
+        Net().LoadParam("/nonexistent/model.param")
+
+
+def test_param_and_bin_files_round_trip(tmp_path):
+    from feathercnn_amd.net import Net
+    p, b, _, _ = model_zoo.tiny_allsorts()
+    (tmp_path / "m.param").write_bytes(p)
+    (tmp_path / "m.bin").write_bytes(b)
+    net = Net()
+    net.LoadParam(str(tmp_path / "m.param"))
+    net.LoadWeights(str(tmp_path / "m.bin"))
+    assert len(net.layers()) == 28

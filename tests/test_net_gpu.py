@@ -1,0 +1,236 @@
+"""Parity of the layers between the convolutions and of the whole-net runtime on the GPU.
+
+Every result is compared with a CPU checker on the same seeded inputs: the committed fixtures the REAL reference
+feather::Net produced (tests/golden/net_golden.npz), the live reference where its prebuilt .so travelled to the box, and
+the numpy/C restatement (oracle.netcheck.PortNet) for batches and for configurations the reference crashes on.
+Tolerance: normalised max error <= 1e-4; elementwise layers are exact or within 1 ulp."""
+import os
+
+import numpy as np
+import pytest
+
+from feathercnn_amd import model_zoo
+from oracle import nerr, netcheck
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_golden.npz")
+TOL = 1e-4
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+# ---- layer kernels -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("count", [1, 3, 4, 1000, 4099, 1 << 20])
+def test_relu_and_add_exact(cuda, count):
+    from feathercnn_amd import net as fnet
+    rng = np.random.default_rng(count)
+    a, b = rng.uniform(-1, 1, count).astype(np.float32), rng.uniform(-1, 1, count).astype(np.float32)
+    ta, tb = _t(a, cuda), _t(b, cuda)
+    assert np.array_equal(fnet.relu(ta).cpu().numpy(), np.maximum(a, 0))
+    assert np.array_equal(fnet.add(ta, tb).cpu().numpy(), a + b)
+    assert np.array_equal(fnet.add(ta, tb, relu=True).cpu().numpy(), np.maximum(a + b, 0))
+    if count > 8:  # unaligned views take the scalar path
+        assert np.array_equal(fnet.relu(ta[1:]).cpu().numpy(), np.maximum(a[1:], 0))
+        assert np.array_equal(fnet.add(ta[1:], tb[1:], relu=True).cpu().numpy(), np.maximum(a[1:] + b[1:], 0))
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 5, 7), (2, 16, 14, 14), (3, 7, 1, 1), (2, 64, 56, 56)])
+def test_affine_matches_reference_formula(cuda, shape):
+    from feathercnn_amd import net as fnet
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    m, a = rng.uniform(0.5, 1.5, shape[1]).astype(np.float32), rng.uniform(-0.1, 0.1, shape[1]).astype(np.float32)
+    want = x * m[None, :, None, None] + a[None, :, None, None]
+    got = fnet.affine(_t(x, cuda), _t(m, cuda), _t(a, cuda)).cpu().numpy()
+    assert np.allclose(got, want, rtol=0, atol=2e-7)
+    got = fnet.affine(_t(x, cuda), _t(m, cuda), None, relu=True).cpu().numpy()
+    assert np.allclose(got, np.maximum(x * m[None, :, None, None], 0), rtol=0, atol=2e-7)
+
+
+POOLS = [  # (c, h, w, kernel, stride, (pl, pr, pt, pb), type, global)
+    (3, 8, 8, 2, 2, (0, 0, 0, 0), 0, False), (4, 112, 112, 3, 2, (0, 0, 0, 0), 0, False), (5, 13, 11, 3, 2, (1, 1, 1, 1), 0, False),
+    (2, 10, 10, 3, 1, (1, 1, 1, 1), 1, False), (3, 9, 7, (3, 2), (1, 2), (0, 0, 1, 0), 1, False), (6, 7, 7, 7, 1, (0, 0, 0, 0), 1, True),
+    (2, 5, 9, 1, 1, (0, 0, 0, 0), 0, True), (2, 6, 6, 2, 2, (1, 0, 0, 1), 1, False)]
+
+
+@pytest.mark.parametrize("case", POOLS)
+def test_pooling_matches_restatement_including_pad_quirk(cuda, case):
+    from feathercnn_amd import net as fnet
+    c, h, w, k, s, pad, typ, glob = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    sh, sw = (s, s) if isinstance(s, int) else s
+    x = np.random.default_rng(7).uniform(-1, 1, (2, c, h, w)).astype(np.float32)
+    pd = {0: typ, 1: kw, 11: kh, 2: sw, 12: sh, 3: pad[0], 14: pad[1], 13: pad[2], 15: pad[3], 4: int(glob)}
+    want = netcheck._pool(x, pd)
+    got = fnet.pooling(_t(x, cuda), fnet.pool_param(c, h, w, (kh, kw), (sh, sw), pad, typ, glob)).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=0, atol=5e-7 if typ else 0)
+
+
+@pytest.mark.parametrize("shape", [(1, 10, 1, 1), (4, 1000, 1, 1), (2, 3, 5, 5), (1, 5000, 1, 1)])
+def test_softmax(cuda, shape):
+    from feathercnn_amd import net as fnet
+    x = np.random.default_rng(2).uniform(-8, 8, shape).astype(np.float32)
+    f = x.reshape(shape[0], -1).astype(np.float64)
+    e = np.exp(f - f.max(axis=1, keepdims=True))
+    want = (e / e.sum(axis=1, keepdims=True)).reshape(shape)
+    got = fnet.softmax(_t(x, cuda)).cpu().numpy()
+    assert nerr(got, want) <= 1e-6
+
+
+# ---- whole nets ----------------------------------------------------------------------------------------------------
+def _run(model, x, out, fusion=1, graph=False, repeat=1):
+    from feathercnn_amd.net import Net
+    p, b, i, _ = model
+    net = Net(fusion=fusion, graph=graph)
+    net.LoadParam(p)
+    net.LoadWeights(b)
+    net.FeedInput(i, x)
+    for _ in range(repeat):
+        net.Forward()
+    return net, net.Extract(out)
+
+
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+@pytest.mark.parametrize("graph", [False, True])
+def test_tiny_net_matches_reference_fixture(cuda, fusion, graph):
+    g = np.load(GOLDEN)
+    model = (g["tiny/param"].tobytes(), g["tiny/bin"].tobytes(), "data", "prob")
+    net, prob = _run(model, g["tiny/x"], "prob", fusion, graph, repeat=3 if graph else 1)
+    assert prob.shape == (2, 10, 1, 1)
+    assert nerr(prob, g["tiny/blob/prob"]) <= TOL
+    survivors = ["pool1", "cat", "drop", "gap", "fc2"] if fusion else [k.split("/")[2] for k in g.files if k.startswith("tiny/blob/")]
+    for name in survivors:
+        assert nerr(net.Extract(name), g["tiny/blob/" + name]) <= TOL, name
+    types = [t for t, _, _ in net.layers()]
+    if fusion == 0:
+        assert len(types) == 28
+    else:
+        assert "ReLU" not in types and types.count("Scale") == (1 if fusion == 1 else 0)
+        assert types.count("BatchNorm") == (2 if fusion == 1 else 0)
+        from feathercnn_amd import FeatherHipError
+        with pytest.raises(FeatherHipError, match="fused"):
+            net.Extract("conv1")  # its consumer relu1 was absorbed: the conv now writes blob relu1
+    algos = {n: a for _, n, a in net.layers()}
+    assert algos["conv1"] == "IM2COL" and algos["conv2"] == "WINOGRADF63" and algos["dw"] == "DEPTHWISE" and algos["fc1"] == "IM2COL"
+
+
+def test_tiny_net_batches_and_reshape(cuda):
+    """Batch > 1 (the reference is N = 1: checker loops), then new batch and new image size through the same Net."""
+    from feathercnn_amd.net import Net
+    p, b, i, o = model_zoo.tiny_allsorts()
+    port = netcheck.PortNet(p, b)
+    net = Net()
+    net.LoadParam(p)
+    net.LoadWeights(b)
+    for shape in [(5, 3, 20, 20), (1, 3, 20, 20), (2, 3, 32, 26), (7, 3, 20, 20)]:
+        x = np.random.default_rng(sum(shape)).uniform(-1, 1, shape).astype(np.float32)
+        net.FeedInput(i, x)
+        net.Forward()
+        got = net.Extract(o)
+        want = port.run(i, x, o)
+        assert got.shape == want.shape
+        assert nerr(got, want) <= TOL, shape
+        assert nerr(net.Extract("cat"), port.run(i, x, "cat")) <= TOL, shape
+    mem = net.memory()
+    assert mem["blob_bytes"] > 0 and mem["weight_bytes"] > 0
+
+
+def test_squeezenet_matches_reference_fixture(cuda):
+    g = np.load(GOLDEN)
+    model = model_zoo.squeezenet_v11()
+    x = np.random.default_rng(43).uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    net, prob = _run(model, x, "prob")
+    assert nerr(prob, g["squeezenet/prob"]) <= TOL
+    assert nerr(net.Extract("fire5_concat")[:, :8], g["squeezenet/fire5"]) <= TOL
+    assert np.argmax(prob[0]) == np.argmax(g["squeezenet/prob"][0])
+    timed = net.forward_timed()
+    assert len(timed) == len(net.layers()) and all(ms >= 0 for *_, ms in timed)
+
+
+@pytest.mark.parametrize("name,batch,size,fusion", [("mobilenet_v1", 3, 224, 1), ("mobilenet_v1", 2, 224, 2), ("resnet50", 2, 224, 1),
+                                                     ("resnet50", 1, 224, 2), ("vgg16", 2, 64, 1)])
+def test_benchmark_nets_match_cpu_checker(cuda, name, batch, size, fusion):
+    """Full benchmark topologies against the live reference (looped over the batch) when its .so is on the box, else the
+    restatement.  Checked before the softmax too: the logits carry the accumulated error of every layer."""
+    model = model_zoo.MODELS[name](size=size)
+    p, b, i, o = model
+    x = np.random.default_rng(11).uniform(-1, 1, (batch, 3, size, size)).astype(np.float32)
+    logits = {"mobilenet_v1": "fc7", "resnet50": "fc1000", "vgg16": "fc8"}[name]
+    net, prob = _run(model, x, o, fusion)
+    got_logits = net.Extract(logits)
+    if netcheck.have_ref_net():
+        ref = netcheck.RefNet(p, b)
+        want, want_logits = ref.run(i, x, o), ref.run(i, x, logits)
+        ref.close()
+    else:
+        blobs = netcheck.PortNet(p, b).run(i, x, o, keep=True)
+        want, want_logits = blobs[o], blobs[logits]
+    assert nerr(got_logits, want_logits) <= TOL
+    assert nerr(prob, want) <= TOL
+    assert np.array_equal(prob.reshape(batch, -1).argmax(1), want.reshape(batch, -1).argmax(1))
+
+
+def test_configurations_the_reference_crashes_on_match_restatement(cuda):
+    """Winograd without bias (NULL bias deref), depthwise WITH bias (2.3 #5), InnerProduct without bias
+    (inner_product_layer.h:91): the product handles them; the restatement is the checker."""
+    g = model_zoo.GraphBuilder(9)
+    x = g.input("data", 8, 18, 18)
+    x = g.conv("wino_nobias", x, 8, 16, 3, 1, 1, bias=False)
+    x = g.relu("r1", x)
+    x = g.conv("dw_bias", x, 16, 16, 3, 2, 1, group=16, bias=True)
+    x = g.pool("gap", x, 9, 1, avg=True, global_=True)
+    x = g.fc("fc_nobias", x, 16, 5, bias=False)
+    p, b = g.finish()
+    img = np.random.default_rng(3).uniform(-1, 1, (3, 8, 18, 18)).astype(np.float32)
+    want = netcheck.PortNet(p, b).run("data", img, "fc_nobias", keep=True)
+    net, got = _run((p, b, "data", None), img, "fc_nobias", fusion=0)
+    for name in ("wino_nobias", "dw_bias", "fc_nobias"):
+        assert nerr(net.Extract(name), want[name]) <= TOL, name
+
+
+def test_fp16_and_codebook_weight_payloads(cuda):
+    """ncnn .bin payload kinds besides raw fp32 (ncnn/modelbin.cpp:78-150): fp16 tag 0x01306B47 and the 256-entry table."""
+    import struct
+    rng = np.random.default_rng(21)
+    w = (rng.uniform(-1, 1, 8 * 4 * 9) * 0.3).astype(np.float32)
+    bias = rng.uniform(-0.1, 0.1, 8).astype(np.float32)
+    param = b"7767517\n2 2\nInput data 0 1 data 0=12 1=12 2=4\nConvolution c 1 1 data c 0=8 1=3 4=1 5=1 6=288\n"
+    img = rng.uniform(-1, 1, (2, 4, 12, 12)).astype(np.float32)
+    w16 = w.astype(np.float16)
+    table = np.linspace(-0.3, 0.3, 256).astype(np.float32)
+    idx = np.abs(w[:, None] - table[None, :]).argmin(1).astype(np.uint8)
+    payloads = {"fp16": (struct.pack("<I", 0x01306B47) + w16.tobytes(), w16.astype(np.float32)),
+                "table": (bytes([1, 0, 0, 0]) + table.tobytes() + idx.tobytes(), table[idx])}
+    for kind, (blob, w_eff) in payloads.items():
+        raw = struct.pack("<I", 0) + w_eff.astype("<f4").tobytes() + bias.tobytes()
+        want = netcheck.PortNet(param, raw).run("data", img, "c")
+        _, got = _run((param, blob + bias.tobytes(), "data", None), img, "c")
+        assert nerr(got, want) <= TOL, kind
+
+
+def test_forward_before_feed_and_unknown_blob_fail_loudly(cuda):
+    from feathercnn_amd import FeatherHipError
+    from feathercnn_amd.net import Net
+    p, b, i, o = model_zoo.tiny_allsorts()
+    net = Net()
+    net.LoadParam(p)
+    with pytest.raises(FeatherHipError, match="weights"):
+        net.Forward()
+    net.LoadWeights(b)
+    with pytest.raises(FeatherHipError, match="not been fed"):
+        net.Forward()
+    with pytest.raises(FeatherHipError, match="Invalid input blob"):
+        net.FeedInput("nope", np.zeros((1, 3, 20, 20), np.float32))
+    net.FeedInput(i, np.zeros((1, 3, 20, 20), np.float32))
+    net.Forward()
+    with pytest.raises(FeatherHipError, match="Cannot find output blob"):
+        net.Extract("nope")
+    with pytest.raises(FeatherHipError, match="input channels"):
+        net.FeedInput(i, np.zeros((1, 4, 20, 20), np.float32))
+        net.Forward()

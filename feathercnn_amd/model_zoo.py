@@ -3,7 +3,7 @@
 The reference ships no model files and there is no network, so whole-net runs use the standard public architectures
 with seeded random weights written in the format ``feather::Net`` loads (SURVEY.md Appendix A; reference
 src/net.cpp:67-170, src/ncnn/paramdict.cpp:92-174, src/ncnn/modelbin.cpp:47-197).  The same files feed the reference
-``feather::Net`` (oracle/_ref) and this package's ``Net``.
+``feather::Net`` (the CPU checker of the tests) and this package's ``Net``.
 
 Weight distribution: He-uniform ``U(-1,1)*sqrt(6/fan_in)`` so activations keep O(1) magnitude through 50 layers;
 bias ``U(-0.1,0.1)``; BatchNorm slope/var ``U(0.5,1.5)``, mean/bias ``U(-0.1,0.1)``.
@@ -16,11 +16,14 @@ import numpy as np
 
 
 class GraphBuilder:
-    def __init__(self, seed: int = 1234):
+    def __init__(self, seed: int = 1234, dry: bool = False):
+        """dry=True: build the .param only and count the .bin bytes (``nbytes``) without drawing any weights."""
         self.rng = np.random.default_rng(seed)
         self.lines: list[str] = []
         self.bin = bytearray()
         self.blob_count = 0
+        self.dry = dry
+        self.nbytes = 0
 
     # -- low level ----------------------------------------------------------------------------------------------
     def layer(self, type_, name, bottoms, tops, params=None):
@@ -30,13 +33,23 @@ class GraphBuilder:
         return tops[0] if tops else None
 
     def _tagged(self, a):  # mb.load(n, 0): 4-byte zero tag + raw fp32
-        self.bin += struct.pack("<I", 0) + np.ascontiguousarray(a, dtype="<f4").tobytes()
+        self.nbytes += 4
+        if not self.dry:
+            self.bin += struct.pack("<I", 0)
+        self._raw(a)
 
     def _raw(self, a):  # mb.load(n, 1)
-        self.bin += np.ascontiguousarray(a, dtype="<f4").tobytes()
+        if self.dry:
+            self.nbytes += 4 * a
+        else:
+            self.bin += np.ascontiguousarray(a, dtype="<f4").tobytes()
+            self.nbytes += 4 * a.size
 
-    def _uniform(self, n, lo, hi):
-        return self.rng.uniform(lo, hi, size=n).astype(np.float32)
+    def _uniform(self, n, lo, hi, scale=None):
+        if self.dry:
+            return n
+        a = self.rng.uniform(lo, hi, size=n).astype(np.float32)
+        return a if scale is None else a * np.float32(scale)
 
     # -- layers -------------------------------------------------------------------------------------------------
     def input(self, name, c, h, w):
@@ -47,7 +60,7 @@ class GraphBuilder:
         wsize = cout * (cin // group) * k * k
         type_ = "ConvolutionDepthWise" if group > 1 else "Convolution"
         top = self.layer(type_, name, [bottom], [top or name], {0: cout, 1: k, 3: s, 4: p, 5: int(bias), 6: wsize, 7: group})
-        self._tagged(self._uniform(wsize, -1, 1) * np.float32(np.sqrt(6.0 / fan_in)))
+        self._tagged(self._uniform(wsize, -1, 1, np.sqrt(6.0 / fan_in)))
         if bias:
             self._raw(self._uniform(cout, -0.1, 0.1))
         return top
@@ -60,7 +73,7 @@ class GraphBuilder:
 
     def fc(self, name, bottom, cin, cout, bias=True):
         top = self.layer("InnerProduct", name, [bottom], [name], {0: cout, 1: int(bias), 2: cin * cout})
-        self._tagged(self._uniform(cin * cout, -1, 1) * np.float32(np.sqrt(6.0 / cin)))
+        self._tagged(self._uniform(cin * cout, -1, 1, np.sqrt(6.0 / cin)))
         if bias:
             self._raw(self._uniform(cout, -0.1, 0.1))
         return top
@@ -108,11 +121,11 @@ class GraphBuilder:
 
     def finish(self):
         text = "7767517\n%d %d\n" % (len(self.lines), self.blob_count) + "\n".join(self.lines) + "\n"
-        return text.encode(), bytes(self.bin)
+        return text.encode(), (self.nbytes if self.dry else bytes(self.bin))  # dry: the .bin size instead of the .bin
 
 
-def vgg16(seed=1234, classes=1000, size=224):
-    g = GraphBuilder(seed)
+def vgg16(seed=1234, classes=1000, size=224, dry=False):
+    g = GraphBuilder(seed, dry)
     x = g.input("data", 3, size, size)
     cin = 3
     for stage, (n, c) in enumerate([(2, 64), (2, 128), (3, 256), (3, 512), (3, 512)], 1):
@@ -127,9 +140,9 @@ def vgg16(seed=1234, classes=1000, size=224):
     return g.finish() + ("data", "prob")
 
 
-def resnet50(seed=1234, classes=1000, size=224):
+def resnet50(seed=1234, classes=1000, size=224, dry=False):
     """Caffe ResNet-50: conv-BN-Scale-ReLU, stride on the first 1x1 of each stage, explicit Split for the shortcut."""
-    g = GraphBuilder(seed)
+    g = GraphBuilder(seed, dry)
     x = g.input("data", 3, size, size)
     x = g.conv_bn_relu("conv1", x, 3, 64, 7, 2, 3)
     x = g.pool("pool1", x, 3, 2)
@@ -151,8 +164,8 @@ def resnet50(seed=1234, classes=1000, size=224):
     return g.finish() + ("data", "prob")
 
 
-def mobilenet_v1(seed=1234, classes=1000, size=224):
-    g = GraphBuilder(seed)
+def mobilenet_v1(seed=1234, classes=1000, size=224, dry=False):
+    g = GraphBuilder(seed, dry)
     x = g.input("data", 3, size, size)
     x = g.conv_bn_relu("conv1", x, 3, 32, 3, 2, 1)
     cfg = [(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2)] + [(512, 512, 1)] * 5 + \
@@ -165,8 +178,8 @@ def mobilenet_v1(seed=1234, classes=1000, size=224):
     return g.finish() + ("data", "prob")
 
 
-def squeezenet_v11(seed=1234, classes=1000, size=224):
-    g = GraphBuilder(seed)
+def squeezenet_v11(seed=1234, classes=1000, size=224, dry=False):
+    g = GraphBuilder(seed, dry)
     x = g.input("data", 3, size, size)
     x = g.relu("relu_conv1", g.conv("conv1", x, 3, 64, 3, 2, 0))
     x = g.pool("pool1", x, 3, 2)
@@ -191,9 +204,9 @@ def squeezenet_v11(seed=1234, classes=1000, size=224):
     return g.finish() + ("data", "prob")
 
 
-def tiny_allsorts(seed=7, size=20):
+def tiny_allsorts(seed=7, size=20, dry=False):
     """A small net touching every registered layer type (layer_factory.cpp:55-67) for the Net parity tests."""
-    g = GraphBuilder(seed)
+    g = GraphBuilder(seed, dry)
     x = g.input("data", 3, size, size)
     x = g.relu("relu1", g.conv("conv1", x, 3, 16, 3, 1, 1))             # IM2COL (C=3)
     x = g.conv_bn_relu("conv2", x, 16, 16, 3, 1, 1)                      # Winograd + BN + Scale + ReLU

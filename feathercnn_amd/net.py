@@ -29,6 +29,9 @@ class Net:
 
     __del__ = close
 
+    def set_graph(self, on: bool):
+        _check(self._lib.fhip_net_set_graph(self._h, int(bool(on))), "fhip_net_set_graph")
+
     def use_current_stream(self):
         """Enqueue on torch's current stream (so torch events and tensors order against the net's work)."""
         _check(self._lib.fhip_net_set_stream(self._h, _stream()), "fhip_net_set_stream")

@@ -30,7 +30,8 @@ def have_ref_net() -> bool:
 
 
 class RefNet:
-    def __init__(self, param: bytes, weights: bytes):
+    def __init__(self, param: bytes | None, weights: bytes | None, param_path: str | None = None, bin_path: str | None = None):
+        """Either the model images (written to a temporary directory) or paths of existing .param/.bin files."""
         lib = ctypes.CDLL(NET_REF_SO)
         lib.ref_net_open.restype = ctypes.c_void_p
         lib.ref_net_open.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -41,11 +42,14 @@ class RefNet:
         lib.ref_net_time.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ref_net_close.argtypes = [ctypes.c_void_p]
         self.lib = lib
-        with tempfile.TemporaryDirectory() as d:
-            pp, bp = os.path.join(d, "m.param"), os.path.join(d, "m.bin")
-            open(pp, "wb").write(param)
-            open(bp, "wb").write(weights)
-            self.h = lib.ref_net_open(pp.encode(), bp.encode())
+        if param_path is not None:
+            self.h = lib.ref_net_open(param_path.encode(), bin_path.encode())
+        else:
+          with tempfile.TemporaryDirectory() as d:
+              pp, bp = os.path.join(d, "m.param"), os.path.join(d, "m.bin")
+              open(pp, "wb").write(param)
+              open(bp, "wb").write(weights)
+              self.h = lib.ref_net_open(pp.encode(), bp.encode())
         if not self.h:
             raise RuntimeError("reference feather::Net failed to load the model")
 

@@ -148,7 +148,7 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f"{f} imports the oracle"
                 assert "conv_port" not in txt and "libfeather_ref" not in txt and "oracle/" not in txt, f"{f} references the oracle"
-    hdr = open(HEADER).read() + open(os.path.join(ROOT, "include", "booster", "booster.h")).read()
+    hdr = "".join(open(h).read() for h in HEADERS) + open(os.path.join(ROOT, "include", "booster", "booster.h")).read()
     assert "oracle" not in hdr
     proc = subprocess.run([sys.executable, "-c", "import sys; import feathercnn_amd; import feathercnn_amd.nets, feathercnn_amd.shard; "
                            "assert 'oracle' not in sys.modules"], cwd=ROOT, capture_output=True, text=True)

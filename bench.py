@@ -258,7 +258,6 @@ def setup_net(a, env):
     """Whole-net mode.  -> (step, finalize)"""
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     from feathercnn_amd import booster, model_zoo
     from feathercnn_amd.net import Net
@@ -266,24 +265,8 @@ def setup_net(a, env):
     batch = a.batch or DEFAULT_BATCH[a.net]
     build = model_zoo.MODELS[a.net]
     # ---- model: generated on rank 0, the .bin broadcast once over RCCL (the only collective of this path) ------------
-    t_bcast, bcast_bytes = 0.0, 0
-    if world == 1:
-        model = build()
-    else:
-        if rank == 0:
-            model = build()
-            blob = torch.frombuffer(bytearray(model[1]), dtype=torch.uint8).to(dev)
-        else:
-            param, nbytes, i, o = build(dry=True)
-            blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(blob, 0)
-        torch.cuda.synchronize()
-        t_bcast, bcast_bytes = time.perf_counter() - t0, blob.numel()
-        if rank != 0:
-            model = (param, blob.cpu().numpy().tobytes(), i, o)
-        del blob
+    from feathercnn_amd.shard import broadcast_model
+    model, t_bcast, bcast_bytes = broadcast_model(build, dev, src=0)
     p, b, in_name, out_name = model
     net = Net(fusion=a.fusion, graph=not a.no_graph)
     net.LoadParam(p)

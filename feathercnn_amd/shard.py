@@ -35,3 +35,33 @@ def broadcast_weights(tensors, src: int = 0):
         t.copy_(flat[off:off + n].view_as(t))
         off += n
     return flat.numel() * flat.element_size()
+
+
+def broadcast_model(build, device=None, src: int = 0):
+    """Whole-net flavour of the same exchange: rank `src` builds the synthetic model (``build()`` ->
+    (param, bin, input, output), feathercnn_amd/model_zoo.py), every other rank builds only the .param and the .bin's size
+    (``build(dry=True)``) and receives the .bin as ONE flat byte broadcast.  -> (model, seconds, bytes broadcast)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return build(), 0.0, 0
+    rank = dist.get_rank()
+    if rank == src:
+        model = build()
+        blob = torch.frombuffer(bytearray(model[1]), dtype=torch.uint8)
+    else:
+        param, nbytes, i, o = build(dry=True)
+        blob = torch.empty(nbytes, dtype=torch.uint8)
+    if device is not None:
+        blob = blob.to(device)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dist.broadcast(blob, src)
+    if device is not None:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank != src:
+        model = (param, blob.cpu().numpy().tobytes(), i, o)
+    return model, dt, blob.numel()

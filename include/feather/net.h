@@ -1,0 +1,89 @@
+// feather/net.h -- C++ host class feather::Net over the MI355X runtime: the reference's public Net API
+// (reference src/net.h:30-70, src/net.cpp) with the same method names, argument meaning and return codes, so code written
+// against the reference links against libfeather_hip.so instead of libfeather.a:
+//
+//     feather::Net net;
+//     net.LoadParam("model.param");  net.LoadWeights("model.bin");
+//     net.FeedInput("data", c, h, w, host_ptr);          // the reference takes an ncnn::Mat (w, h, c); see below
+//     net.Forward();
+//     float* out; int n, c, h, w;  net.Extract("prob", &out, &n, &c, &h, &w);
+//
+// Differences, all forced by the GPU batch path:
+//   * blobs live in HBM: Extract(name, float**, ...) returns a DEVICE pointer (use ExtractHost for a host copy);
+//   * FeedInput takes plain pointers and an explicit batch instead of an ncnn::Mat (the reference is N = 1, net.cpp:235-246);
+//     the Mat layout [c][h][w] dense is what the pointer form expects -- pass mat.data when cstep == w*h;
+//   * Forward only enqueues work on the net's HIP stream (SetStream); ExtractHost / Synchronize wait for it;
+//   * SetFusion: 0 = none (what the reference actually does: TryFuse is never called),
+//     1 = the reference's declared Conv-ReLU / BN-Scale-ReLU / InnerProduct-ReLU patterns (default), 2 = also fold
+//     BatchNorm/Scale into the preceding convolution's weights.
+// Header-only: every method forwards to the C-ABI in feather_hip/feather_net.h.
+#pragma once
+
+#include <stdio.h>
+
+#include <string>
+
+#include "feather_hip/feather_net.h"
+
+namespace feather
+{
+
+class Net
+{
+  public:
+    Net() : net_(NULL) { fhip_net_create(&net_); }
+    ~Net()
+    {
+        if (net_) fhip_net_destroy(net_);
+    }
+
+    // Net::LoadParam / LoadWeights (net.cpp:54-233): 0 on success, negative on failure (-1 I/O, -200 unknown layer,
+    // -300 topology error, -100 bad layer parameters), message in LastError().
+    int LoadParam(const char* param_path) { return fhip_net_load_param(net_, param_path); }
+    int LoadParam(FILE* fp) { return load_file(fp, true); }
+    int LoadWeights(const char* weights_path) { return fhip_net_load_weights(net_, weights_path); }
+    int LoadWeights(FILE* fp) { return load_file(fp, false); }
+    int LoadParamMem(const char* text, size_t len) { return fhip_net_load_param_mem(net_, text, len); }
+    int LoadWeightsMem(const void* data, size_t len) { return fhip_net_load_weights_mem(net_, data, len); }
+
+    // Net::FeedInput (net.cpp:235-246).  `data` = n*c*h*w floats, NCHW dense, host memory.
+    int FeedInput(const char* input_name, int c, int h, int w, const float* data) { return fhip_net_feed_input(net_, input_name, 1, c, h, w, data, 0); }
+    int FeedInput(const char* input_name, int n, int c, int h, int w, const float* data) { return fhip_net_feed_input(net_, input_name, n, c, h, w, data, 0); }
+    int FeedInputDevice(const char* input_name, int n, int c, int h, int w, const float* device_data)
+    {
+        return fhip_net_feed_input(net_, input_name, n, c, h, w, device_data, 1);
+    }
+
+    int Forward() { return fhip_net_forward(net_); } // net.cpp:297-334
+
+    // Net::Extract(name, float**, n, c, h, w), net.cpp:263-279; *output_ptr is a DEVICE pointer.
+    int Extract(std::string blob_name, float** output_ptr, int* n, int* c, int* h, int* w)
+    {
+        return fhip_net_extract(net_, blob_name.c_str(), output_ptr, n, c, h, w);
+    }
+    int ExtractHost(std::string blob_name, float* host, size_t capacity_floats) { return fhip_net_extract_host(net_, blob_name.c_str(), host, capacity_floats); }
+
+    int SetStream(void* hip_stream) { return fhip_net_set_stream(net_, hip_stream); }
+    int SetFusion(int level) { return fhip_net_set_fusion(net_, level); }
+    int SetGraph(bool on) { return fhip_net_set_graph(net_, on ? 1 : 0); }
+    int LayerCount() { return fhip_net_layer_count(net_); }
+    static const char* LastError() { return fhip_last_error(); }
+    fhip_net* handle() { return net_; }
+
+  private:
+    Net(const Net&);
+    Net& operator=(const Net&);
+    int load_file(FILE* fp, bool param)
+    {
+        if (!fp) return -1;
+        std::string buf;
+        char chunk[1 << 16];
+        size_t got;
+        if (param) fseek(fp, 0, SEEK_SET); // ChkParamHeader rewinds too (utils.cpp:29)
+        while ((got = fread(chunk, 1, sizeof(chunk), fp)) > 0) buf.append(chunk, got);
+        return param ? fhip_net_load_param_mem(net_, buf.data(), buf.size()) : fhip_net_load_weights_mem(net_, buf.data(), buf.size());
+    }
+    fhip_net* net_;
+};
+
+} // namespace feather

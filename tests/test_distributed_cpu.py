@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from feathercnn_amd.shard import broadcast_weights, shard_range
+from feathercnn_amd.shard import broadcast_model, broadcast_weights, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -38,7 +38,17 @@ def _worker(rank, world, port, q):
         # a data-path-free reduction only to CHECK the shards (the product path has no collective)
         s = torch.tensor([batch.sum().item()], dtype=torch.float64)
         dist.all_reduce(s)
-        q.put((rank, nbytes, digest, lo, hi, float(s.item())))
+        # whole-net flavour: only rank 0 draws the weights; the others get the .bin as one flat broadcast and their
+        # host-side readers must accept it
+        import hashlib
+
+        from feathercnn_amd import model_zoo
+        from feathercnn_amd.net import Net
+        (param, blob, _, _), _, sent = broadcast_model(model_zoo.tiny_allsorts)
+        net = Net()
+        net.LoadParam(param)
+        net.LoadWeights(blob)
+        q.put((rank, nbytes, digest, lo, hi, float(s.item()), sent, hashlib.sha256(param + blob).hexdigest(), len(net.layers())))
     finally:
         dist.destroy_process_group()
 
@@ -56,7 +66,9 @@ def test_two_ranks_gloo_broadcast_and_shard():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, nb0, d0, lo0, hi0, s0), (r1, nb1, d1, lo1, hi1, s1) = res
+    (r0, nb0, d0, lo0, hi0, s0, *m0), (r1, nb1, d1, lo1, hi1, s1, *m1) = res
+    from feathercnn_amd import model_zoo
+    assert m0 == m1 and m0[0] == len(model_zoo.tiny_allsorts()[1]) and m0[2] == 28, "rank 1 did not receive rank 0's model"
     assert nb0 == nb1 == (8 * 4 * 9 + 8 + 16 * 8) * 4
     assert d0 == d1, "rank 1 did not receive rank 0's weights"
     g = torch.Generator().manual_seed(100)

@@ -114,3 +114,20 @@ def test_param_and_bin_files_round_trip(tmp_path):
     net.LoadParam(str(tmp_path / "m.param"))
     net.LoadWeights(str(tmp_path / "m.bin"))
     assert len(net.layers()) == 28
+
+
+def test_cpp_net_class_compiles_and_reads_models(tmp_path):
+    """include/feather/net.h (the reference's feather::Net API, header-only over the C-ABI) with plain g++, host side only."""
+    import subprocess
+
+    from feathercnn_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p, b, _, _ = model_zoo.tiny_allsorts()
+    (tmp_path / "m.param").write_bytes(p)
+    (tmp_path / "m.bin").write_bytes(b)
+    exe = str(tmp_path / "net_api_test")
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "net_api_test.cpp"),
+                    "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe, str(tmp_path / "m.param"), str(tmp_path / "m.bin")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "net api ok" in out.stdout, out.stdout + out.stderr

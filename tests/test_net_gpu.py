@@ -234,3 +234,25 @@ def test_forward_before_feed_and_unknown_blob_fail_loudly(cuda):
     with pytest.raises(FeatherHipError, match="input channels"):
         net.FeedInput(i, np.zeros((1, 4, 20, 20), np.float32))
         net.Forward()
+
+
+def test_cpp_net_class_forward(cuda, tmp_path):
+    """The C++ feather::Net class end to end: LoadParam(FILE*) / LoadWeights / FeedInput / Forward / Extract, checked against
+    the reference fixture."""
+    import subprocess
+
+    from feathercnn_amd import _lib
+    g = np.load(GOLDEN)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "m.param").write_bytes(g["tiny/param"].tobytes())
+    (tmp_path / "m.bin").write_bytes(g["tiny/bin"].tobytes())
+    g["tiny/x"].astype("<f4").tofile(str(tmp_path / "x.f32"))
+    exe = str(tmp_path / "net_api_test")
+    libdir = os.path.dirname(_lib.lib_path())
+    subprocess.run(["g++", "-std=c++11", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "net_api_test.cpp"),
+                    "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe, str(tmp_path / "m.param"), str(tmp_path / "m.bin"), str(tmp_path / "x.f32"), "2", "3", "20", "20", "prob",
+                          str(tmp_path / "y.f32")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "net forward ok 2 10 1 1" in out.stdout, out.stdout + out.stderr
+    y = np.fromfile(str(tmp_path / "y.f32"), "<f4").reshape(2, 10, 1, 1)
+    assert nerr(y, g["tiny/blob/prob"]) <= TOL

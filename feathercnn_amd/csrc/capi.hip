@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "feather_hip/feather_net.h"
 
 namespace fhip
 {
@@ -18,7 +19,8 @@ int winograd_transform_kernel(const fhip_conv_param& p, float* u, const float* k
 int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, const float* input, hipStream_t s);
 int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const float* u, const float* v, hipStream_t s);
 int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
-                              hipStream_t s);
+                              hipStream_t s, int pool = 0);
+bool winograd_can_pool(const fhip_conv_param& p);
 int winograd_fused_gemm_output(const fhip_conv_param& p, int batch, float* output, const float* u, const float* v, const float* bias,
                                hipStream_t s);
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
@@ -276,11 +278,13 @@ int fhip_conv_init(const fhip_conv_param* p, int algo, float* packed, const floa
     }
 }
 
-int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* output, const float* input, const float* packed,
-                      float* buffer, const float* bias, void* stream)
+static int conv_forward_impl(const fhip_conv_param* p, int algo, int batch, float* output, const float* input, const float* packed,
+                             float* buffer, const float* bias, void* stream, int pool)
 {
     if (!valid_param(p) || !output || !input || !packed || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
+    if (pool && (algo != FHIP_WINOGRADF63 || !winograd_can_pool(*p)))
+        return fail(FHIP_E_UNSUPPORTED, "fused max pooling is available on the Winograd route with even output dims only");
     switch (algo)
     {
         case FHIP_NAIVE: return igemm_forward(*p, batch, output, input, packed, bias, buffer, true, s);
@@ -298,7 +302,7 @@ int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* outp
             int rc = wino_split(*p, batch, &sp);
             if (rc) return rc;
             const size_t in_img = (size_t)p->input_channels * p->input_h * p->input_w;
-            const size_t out_img = (size_t)p->output_channels * p->output_h * p->output_w;
+            const size_t out_img = (size_t)p->output_channels * p->output_h * p->output_w / (pool ? 4 : 1);
             WinoAux* aux = (sp.n > 1 && !fused_env) ? wino_aux() : nullptr;
             if (!aux)
             {
@@ -310,13 +314,13 @@ int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* outp
                     const float* in_b = input + (size_t)sp.first[i] * in_img;
                     float* out_b = output + (size_t)sp.first[i] * out_img;
                     if ((rc = winograd_input_transform(*p, sp.count[i], v, in_b, s))) return rc;
-                    if (fused_env)
+                    if (fused_env && !pool)
                     {
                         if ((rc = winograd_fused_gemm_output(*p, sp.count[i], out_b, packed, v, bias, s))) return rc;
                         continue;
                     }
                     if ((rc = winograd_tile_gemm(*p, sp.count[i], m, packed, v, s))) return rc;
-                    if ((rc = winograd_output_transform(*p, sp.count[i], out_b, m, bias, s))) return rc;
+                    if ((rc = winograd_output_transform(*p, sp.count[i], out_b, m, bias, s, pool))) return rc;
                 }
                 return FHIP_OK;
             }
@@ -344,13 +348,30 @@ int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* outp
                     float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.m_off[j]);
                     float* out_b = output + (size_t)sp.first[j] * out_img;
                     FHIP_CHECK_HIP(hipStreamWaitEvent(s, aux->e3[j], 0));
-                    if ((rc = winograd_output_transform(*p, sp.count[j], out_b, m, bias, s))) return rc;
+                    if ((rc = winograd_output_transform(*p, sp.count[j], out_b, m, bias, s, pool))) return rc;
                 }
             }
             return FHIP_OK;
         }
         default: return fail(FHIP_E_UNSUPPORTED, "This algo is not supported on gfx950");
     }
+}
+
+int fhip_conv_forward(const fhip_conv_param* p, int algo, int batch, float* output, const float* input, const float* packed,
+                      float* buffer, const float* bias, void* stream)
+{
+    return conv_forward_impl(p, algo, batch, output, input, packed, buffer, bias, stream, 0);
+}
+
+int fhip_conv_forward_maxpool2(const fhip_conv_param* p, int algo, int batch, float* pooled_output, const float* input, const float* packed,
+                               float* buffer, const float* bias, void* stream)
+{
+    return conv_forward_impl(p, algo, batch, pooled_output, input, packed, buffer, bias, stream, 1);
+}
+
+int fhip_conv_can_fuse_maxpool2(const fhip_conv_param* p, int algo)
+{
+    return valid_param(p) && algo == FHIP_WINOGRADF63 && winograd_can_pool(*p) ? 1 : 0;
 }
 
 int fhip_winograd_f63_transform_kernel(const fhip_conv_param* p, float* u, const float* kernel, void* stream)

@@ -223,7 +223,10 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
     const int kt = kdp / kConvKTile;
     if (tiles >= 512 || kt < 16) return 1;
-    const int want = (int)std::min<long long>(8, (768 + tiles - 1) / tiles);
+    // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 32 tiles x 1568) stream the weight
+    // matrix once and are HBM bound: they want many more blocks in flight than the conv layers do
+    const bool deep = kt >= 512;
+    const int want = (int)std::min<long long>(deep ? 32 : 8, ((deep ? 2048 : 768) + tiles - 1) / tiles);
     int best = 1;
     for (int s = 2; s <= want; ++s)
         if (kt % s == 0 && kt / s >= 8) best = s;

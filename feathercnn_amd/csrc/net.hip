@@ -385,8 +385,17 @@ struct ConvLayer : Layer
     std::vector<float> post_mul, post_add; // folded BatchNorm/Scale (fusion level 2)
     DeviceVec packed, bias;
     size_t buffer_bytes = 0, packed_bytes = 0;
+    // fusion level 2: a following 2x2 / stride-2 max pooling is absorbed (fhip_conv_forward_maxpool2 when the route can,
+    // else this layer runs conv -> pre_pool -> fhip_pooling itself)
+    bool fuse_pool = false, pool_fast = false;
+    fhip_pool_param poolq;
+    DeviceVec pre_pool;
 
-    ConvLayer() { memset(&p, 0, sizeof(p)); }
+    ConvLayer()
+    {
+        memset(&p, 0, sizeof(p));
+        memset(&poolq, 0, sizeof(poolq));
+    }
 
     int LoadParam(const ParamDict& pd) override
     {
@@ -434,9 +443,21 @@ struct ConvLayer : Layer
             return failf(NET_E_TOPOLOGY, "convolution layer %s has %d input channels while bottom blob has %d channels", name.c_str(), p.input_channels, b->c);
         fhip_conv_assign_output_dim(&p);
         if (p.output_h < 1 || p.output_w < 1) return failf(NET_E_SHAPE, "layer %s: empty output", name.c_str());
-        int rc = tops[0]->reshape(b->n, p.output_channels, p.output_h, p.output_w);
+        int rc = fhip_conv_select_algo(&p, &algo_);
         if (rc) return rc;
-        rc = fhip_conv_select_algo(&p, &algo_);
+        if (fuse_pool)
+        {
+            poolq.channels = p.output_channels;
+            poolq.input_h = p.output_h;
+            poolq.input_w = p.output_w;
+            int ph, pw;
+            if ((rc = fhip_pooling_output_dim(&poolq, &ph, &pw))) return rc;
+            pool_fast = fhip_conv_can_fuse_maxpool2(&p, algo_) != 0;
+            if (!pool_fast && (rc = pre_pool.resize((size_t)b->n * p.output_channels * p.output_h * p.output_w * sizeof(float)))) return rc;
+            rc = tops[0]->reshape(b->n, p.output_channels, ph, pw);
+        }
+        else
+            rc = tops[0]->reshape(b->n, p.output_channels, p.output_h, p.output_w);
         if (rc) return rc;
         return fhip_conv_get_buffer_size(&p, algo_, b->n, &buffer_bytes, &packed_bytes);
     }
@@ -474,11 +495,16 @@ struct ConvLayer : Layer
     }
     int Forward(hipStream_t s) override
     {
-        return fhip_conv_forward(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d,
-                                 p.bias_term ? bias.d : nullptr, s);
+        const float* b = p.bias_term ? bias.d : nullptr;
+        if (!fuse_pool) return fhip_conv_forward(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
+        if (pool_fast)
+            return fhip_conv_forward_maxpool2(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
+        const int rc = fhip_conv_forward(&p, algo_, bottoms[0]->n, pre_pool.d, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
+        if (rc) return rc;
+        return fhip_pooling(&poolq, bottoms[0]->n, tops[0]->data, pre_pool.d, s);
     }
     int Fuse(Layer* next, int level) override;
-    size_t weight_bytes() const override { return packed.bytes + bias.bytes; }
+    size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes; }
     size_t arena_bytes() const override { return buffer_bytes; }
     int algo() const override { return algo_; }
 };
@@ -727,6 +753,17 @@ struct ScaleLayer : AffineLayer
 
 int ConvLayer::Fuse(Layer* next, int level)
 {
+    if (fuse_pool) return 0; // nothing is absorbed behind the pooling
+    if (level >= 2 && next->type == "Pooling")
+    {
+        const fhip_pool_param& q = static_cast<PoolingLayer*>(next)->q;
+        if (q.pooling_type != 0 || q.global_pooling || q.kernel_h != 2 || q.kernel_w != 2 || q.stride_h != 2 || q.stride_w != 2 || q.pad_left ||
+            q.pad_right || q.pad_top || q.pad_bottom)
+            return 0;
+        poolq = q;
+        fuse_pool = true;
+        return 1;
+    }
     if (next->type == "ReLU")
     {
         p.activation = FHIP_ACT_RELU;

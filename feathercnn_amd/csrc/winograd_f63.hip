@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __rest
 struct WinoStaged
 {
     int UB;    // units per block
-    int LDW;   // LDS row pitch (floats): >= 6*TX, multiple of 4
+    int LDW;   // LDS row pitch (floats): >= R*TX, multiple of 4
     int units; // N * TY
     int TY;
+    int R;     // staged rows per unit: 6, or 3 when the 2x2 max pooling is fused
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -225,14 +226,16 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(float* __res
 // writes 6-float pieces at a 24-byte lane stride: 36 store instructions per lane, each touching 12 cache lines;
 // measured 3.3 TB/s effective on VGG conv1_2 against ~5 TB/s for the coalesced input transform.)
 
-template <bool HAS_BIAS, bool RELU>
+// POOL: the 6x6 tile is reduced by a 2x2 / stride-2 max in registers before it is staged, so the block writes 3 x OW/2
+// pooled rows per unit and the full-resolution output never exists (OH, OW even: pooled cells never straddle the edge).
+template <bool HAS_BIAS, bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float* __restrict__ out, const float* __restrict__ M,
                                                                           const float* __restrict__ bias,
                                                                           const WinoXformParams q, const WinoStaged g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const tile = smem;                                             // [UB][6][LDW]
-    long long* const ubase = reinterpret_cast<long long*>(smem + (size_t)g.UB * 6 * g.LDW); // [UB] output offset of the unit's first row
+    float* const tile = smem;                                             // [UB][R][LDW], R = 6 (3 when pooled)
+    long long* const ubase = reinterpret_cast<long long*>(smem + (size_t)g.UB * g.R * g.LDW); // [UB] output offset of the unit's first row
     int* const urows = reinterpret_cast<int*>(ubase + g.UB);              // [UB] valid rows (0 = unit beyond the tensor)
 
     const int tid = threadIdx.x;
@@ -248,6 +251,11 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
             const int n = u / g.TY, ty = u - n * g.TY;
             rows = min(6, q.OH - 6 * ty);
             base = (((long long)n * q.K + k) * q.OH + 6 * ty) * q.OW;
+            if (POOL)
+            {
+                rows >>= 1;
+                base = (((long long)n * q.K + k) * (q.OH >> 1) + 3 * ty) * (q.OW >> 1);
+            }
         }
         ubase[tid] = base;
         urows[tid] = rows;
@@ -271,7 +279,8 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
             at6(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], m[6][j], m[7][j], tmp[0][j], tmp[1][j], tmp[2][j],
                 tmp[3][j], tmp[4][j], tmp[5][j]);
         const float b = HAS_BIAS ? bias[k] : 0.f;
-        float* tp = tile + ((size_t)unit_l * 6) * g.LDW + 6 * tx;
+        float* tp = tile + ((size_t)unit_l * g.R) * g.LDW + (POOL ? 3 : 6) * tx;
+        float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
         {
@@ -285,6 +294,24 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
                 if (RELU) v = fmaxf(v, 0.f);
                 y[bb] = v;
             }
+            if (POOL)
+            {
+                const float h0 = fmaxf(y[0], y[1]), h1 = fmaxf(y[2], y[3]), h2 = fmaxf(y[4], y[5]);
+                if ((a & 1) == 0)
+                {
+                    prev0 = h0;
+                    prev1 = h1;
+                    prev2 = h2;
+                }
+                else
+                {
+                    float* t = tp + (size_t)(a >> 1) * g.LDW;
+                    t[0] = fmaxf(prev0, h0);
+                    t[1] = fmaxf(prev1, h1);
+                    t[2] = fmaxf(prev2, h2);
+                }
+                continue;
+            }
             // 6*tx floats = 24*tx bytes: 8-byte aligned
             float2* t2 = reinterpret_cast<float2*>(tp + (size_t)a * g.LDW);
             t2[0] = make_float2(y[0], y[1]);
@@ -295,29 +322,30 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
     __syncthreads();
 
     // LDS -> global: every valid output row of the block, OW floats each, consecutive lanes on consecutive addresses
-    if ((q.OW & 3) == 0)
+    const int R = POOL ? 3 : 6, OWo = POOL ? q.OW >> 1 : q.OW;
+    if ((OWo & 3) == 0)
     {
-        const int w4 = q.OW >> 2;
-        const int total = g.UB * 6 * w4;
+        const int w4 = OWo >> 2;
+        const int total = g.UB * R * w4;
         for (int idx = tid; idx < total; idx += 256)
         {
             const int row = idx / w4, x4 = idx - row * w4;
-            const int ul = row / 6, a = row - ul * 6;
+            const int ul = row / R, a = row - ul * R;
             if (a < urows[ul])
             {
-                const float4 v = *reinterpret_cast<const float4*>(tile + ((size_t)ul * 6 + a) * g.LDW + 4 * x4);
-                *reinterpret_cast<float4*>(out + ubase[ul] + (long long)a * q.OW + 4 * x4) = v;
+                const float4 v = *reinterpret_cast<const float4*>(tile + ((size_t)ul * R + a) * g.LDW + 4 * x4);
+                *reinterpret_cast<float4*>(out + ubase[ul] + (long long)a * OWo + 4 * x4) = v;
             }
         }
     }
     else
     {
-        const int total = g.UB * 6 * q.OW;
+        const int total = g.UB * R * OWo;
         for (int idx = tid; idx < total; idx += 256)
         {
-            const int row = idx / q.OW, x = idx - row * q.OW;
-            const int ul = row / 6, a = row - ul * 6;
-            if (a < urows[ul]) out[ubase[ul] + (long long)a * q.OW + x] = tile[((size_t)ul * 6 + a) * g.LDW + x];
+            const int row = idx / OWo, x = idx - row * OWo;
+            const int ul = row / R, a = row - ul * R;
+            if (a < urows[ul]) out[ubase[ul] + (long long)a * OWo + x] = tile[((size_t)ul * R + a) * g.LDW + x];
         }
     }
 }
@@ -438,8 +466,28 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     return FHIP_OK;
 }
 
+template <bool POOL>
+static void launch_staged(dim3 grid, size_t lds, hipStream_t s, bool has_bias, bool relu, float* output, const float* m, const float* bias,
+                          const WinoXformParams& q, const WinoStaged& g)
+{
+    if (has_bias && relu)
+        hipLaunchKernelGGL((wino_output_transform_staged_kernel<true, true, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g);
+    else if (has_bias)
+        hipLaunchKernelGGL((wino_output_transform_staged_kernel<true, false, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g);
+    else if (relu)
+        hipLaunchKernelGGL((wino_output_transform_staged_kernel<false, true, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g);
+    else
+        hipLaunchKernelGGL((wino_output_transform_staged_kernel<false, false, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g);
+}
+
+bool winograd_can_pool(const fhip_conv_param& p)
+{
+    return (p.output_h % 2) == 0 && (p.output_w % 2) == 0 && ceil_div(p.output_w, 6) <= 256;
+}
+
+// pool != 0: `output` is the 2x2 / stride-2 max-pooled tensor [N][K][OH/2][OW/2] (winograd_can_pool must hold)
 int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
-                              hipStream_t s)
+                              hipStream_t s, int pool)
 {
     fhip_winograd_plan pl;
     int rc = winograd_plan(p, batch, &pl);
@@ -447,6 +495,7 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
     const WinoXformParams q = xform_params(p, batch, pl);
     const bool has_bias = p.bias_term != 0, relu = p.activation == FHIP_ACT_RELU;
     if (has_bias && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    if (pool && !winograd_can_pool(p)) return fail(FHIP_E_UNSUPPORTED, "fused 2x2 max pooling needs even output dims");
     StageTimer tm(FHIP_STAGE_WINO_OUTPUT, s);
     if (q.TX <= 256)
     {
@@ -454,20 +503,18 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
         g.TY = pl.tiles_y;
         g.units = batch * pl.tiles_y;
         g.UB = min(256 / q.TX, g.units);
-        g.LDW = round_up(6 * q.TX, 4);
-        const size_t lds = (size_t)g.UB * 6 * g.LDW * sizeof(float) + (size_t)g.UB * (sizeof(long long) + sizeof(int));
+        g.R = pool ? 3 : 6;
+        g.LDW = round_up(g.R * q.TX, 4);
+        const size_t lds = (size_t)g.UB * g.R * g.LDW * sizeof(float) + (size_t)g.UB * (sizeof(long long) + sizeof(int));
         dim3 sgrid(ceil_div(g.units, g.UB), q.K);
-        if (has_bias && relu)
-            hipLaunchKernelGGL((wino_output_transform_staged_kernel<true, true>), sgrid, dim3(256), lds, s, output, m, bias, q, g);
-        else if (has_bias)
-            hipLaunchKernelGGL((wino_output_transform_staged_kernel<true, false>), sgrid, dim3(256), lds, s, output, m, bias, q, g);
-        else if (relu)
-            hipLaunchKernelGGL((wino_output_transform_staged_kernel<false, true>), sgrid, dim3(256), lds, s, output, m, bias, q, g);
+        if (pool)
+            launch_staged<true>(sgrid, lds, s, has_bias, relu, output, m, bias, q, g);
         else
-            hipLaunchKernelGGL((wino_output_transform_staged_kernel<false, false>), sgrid, dim3(256), lds, s, output, m, bias, q, g);
+            launch_staged<false>(sgrid, lds, s, has_bias, relu, output, m, bias, q, g);
         FHIP_CHECK_HIP(hipGetLastError());
         return FHIP_OK;
     }
+    if (pool) return fail(FHIP_E_UNSUPPORTED, "pooled output transform needs the staged kernel");
     dim3 grid(ceil_div(q.P, 256), q.K);
     if (has_bias && relu)
         hipLaunchKernelGGL((wino_output_transform_kernel<true, true>), grid, dim3(256), 0, s, output, m, bias, q);

@@ -29,6 +29,16 @@ FHIP_API int fhip_add(float* y, const float* a, const float* b, size_t count, in
 FHIP_API int fhip_affine(float* y, const float* x, const float* mul, const float* add, int batch, int channels, int hw,
                          int relu, void* stream);
 
+/* Convolution (+bias, +ReLU as the param says) followed by a 2x2 / stride-2 / unpadded MAX pooling, fused: the pooled
+ * tensor [N][K][OH/2][OW/2] is written straight from the Winograd output transform and the full-resolution activation
+ * never reaches HBM (VGG: every pooling layer follows a 3x3 convolution).  Same arguments as fhip_conv_forward.  Only the
+ * WINOGRADF63 route with even output dims can do it: fhip_conv_can_fuse_maxpool2 returns 1 when it can, and
+ * fhip_conv_forward_maxpool2 returns FHIP_E_UNSUPPORTED otherwise (run fhip_conv_forward + fhip_pooling instead).
+ * Equal to ConvLayer::Forward + PoolingLayer::Forward of the reference (conv_layer.h:141-150, pooling_layer.h:37-88). */
+FHIP_API int fhip_conv_can_fuse_maxpool2(const fhip_conv_param* param, int algo);
+FHIP_API int fhip_conv_forward_maxpool2(const fhip_conv_param* param, int algo, int batch, float* pooled_output, const float* input,
+                                        const float* packed, float* buffer, const float* bias, void* stream);
+
 /* PoolingLayer, layers/pooling_layer.h:90-131 (fields as its LoadParam reads them). */
 typedef struct fhip_pool_param
 {

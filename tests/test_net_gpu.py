@@ -154,7 +154,7 @@ def test_squeezenet_matches_reference_fixture(cuda):
 
 
 @pytest.mark.parametrize("name,batch,size,fusion", [("mobilenet_v1", 3, 224, 1), ("mobilenet_v1", 2, 224, 2), ("resnet50", 2, 224, 1),
-                                                     ("resnet50", 1, 224, 2), ("vgg16", 2, 64, 1)])
+                                                     ("resnet50", 1, 224, 2), ("vgg16", 2, 64, 1), ("vgg16", 3, 64, 2)])
 def test_benchmark_nets_match_cpu_checker(cuda, name, batch, size, fusion):
     """Full benchmark topologies against the live reference (looped over the batch) when its .so is on the box, else the
     restatement.  Checked before the softmax too: the logits carry the accumulated error of every layer."""
@@ -256,3 +256,58 @@ def test_cpp_net_class_forward(cuda, tmp_path):
     assert out.returncode == 0 and "net forward ok 2 10 1 1" in out.stdout, out.stdout + out.stderr
     y = np.fromfile(str(tmp_path / "y.f32"), "<f4").reshape(2, 10, 1, 1)
     assert nerr(y, g["tiny/blob/prob"]) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 20, 20), (16, 64, 36, 28), (4, 8, 16, 44), (32, 32, 14, 14), (8, 8, 12, 10)])
+def test_conv_with_fused_maxpool_equals_conv_then_pool(cuda, shape):
+    """fhip_conv_forward_maxpool2 (Winograd output transform writing the pooled tensor) == ConvLayer + PoolingLayer."""
+    import ctypes
+
+    import torch
+    from feathercnn_amd import ConvLayer, ConvParam, _lib
+    from feathercnn_amd import net as fnet
+    c, k, h, w = shape
+    rng = np.random.default_rng(h * w)
+    x = rng.uniform(-1, 1, (3, c, h, w)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (k, c, 3, 3)) / np.sqrt(c * 9)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+    for act in (0, 1):
+        p = ConvParam.make(c, k, h, 3, 1, 1, bias=True, act=act, w=w, batch=3)
+        lyr = ConvLayer(p, _t(wt, cuda), _t(b, cuda))
+        full = lyr.Forward(_t(x, cuda))
+        want = fnet.pooling(full, fnet.pool_param(k, h, w, 2, 2)).cpu().numpy()
+        lib = _lib.load_library()
+        cp = p._c()
+        assert lib.fhip_conv_can_fuse_maxpool2(ctypes.byref(cp), lyr.booster.algo) == 1
+        pooled = torch.empty((3, k, h // 2, w // 2), device=cuda)
+        scratch = torch.empty(max(lyr.buffer_bytes // 4, 1), device=cuda)
+        rc = lib.fhip_conv_forward_maxpool2(ctypes.byref(cp), lyr.booster.algo, 3, pooled.data_ptr(), _t(x, cuda).data_ptr(), lyr.packed.data_ptr(),
+                                            scratch.data_ptr(), lyr.bias.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(pooled.cpu().numpy(), want)  # same arithmetic, max is exact
+    odd = ConvParam.make(c, k, 15, 3, 1, 1, bias=True, act=1, batch=1)
+    assert _lib.load_library().fhip_conv_can_fuse_maxpool2(ctypes.byref(odd._c()), 4) == 0
+
+
+def test_fused_pool_fallback_on_odd_dims_and_non_winograd(cuda):
+    """Fusion level 2 absorbs conv -> (ReLU) -> maxpool 2x2/s2 everywhere; where the fast kernel cannot apply (odd output dims:
+    ceil-mode partial windows; IM2COL route) the layer runs conv + pooling itself.  Checked against the restatement."""
+    g = model_zoo.GraphBuilder(17)
+    x = g.input("data", 3, 15, 15)
+    x = g.relu("r0", g.conv("c0", x, 3, 8, 3, 1, 1))        # IM2COL (C = 3), 15x15 -> pool -> 8x8 (ceil)
+    x = g.pool("p0", x, 2, 2)
+    x = g.relu("r1", g.conv("c1", x, 8, 8, 3, 1, 1))        # 8x8: H <= 8 -> IM2COL, even dims
+    x = g.pool("p1", x, 2, 2)
+    x = g.conv("c2", x, 8, 12, 3, 1, 4)                     # 4x4 pad 4 -> 10x10: Winograd, even: fast path (no ReLU)
+    x = g.pool("p2", x, 2, 2)
+    x = g.relu("r3", g.conv("c3", x, 12, 12, 3, 1, 4))      # 5x5 pad 4 -> 11x11: Winograd, odd: fallback
+    x = g.pool("p3", x, 2, 2)
+    p, b = g.finish()
+    img = np.random.default_rng(4).uniform(-1, 1, (3, 3, 15, 15)).astype(np.float32)
+    want = netcheck.PortNet(p, b).run("data", img, "p3", keep=True)
+    net, got = _run((p, b, "data", None), img, "p3", fusion=2)
+    assert [t for t, _, _ in net.layers()] == ["Input", "Convolution", "Convolution", "Convolution", "Convolution"]
+    assert got.shape == want["p3"].shape == (3, 12, 6, 6)
+    for name in ("p0", "p1", "p2", "p3"):
+        assert nerr(net.Extract(name), want[name]) <= TOL, name

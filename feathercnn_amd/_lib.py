@@ -60,6 +60,8 @@ SIGNATURES = {
     "fhip_relu": (_I, [_V, _V, _SZ, _V]),
     "fhip_add": (_I, [_V, _V, _V, _SZ, _I, _V]),
     "fhip_affine": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V]),
+    "fhip_conv_can_fuse_residual": (_I, [_P, _I]),
+    "fhip_conv_forward_residual": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_maxpool2": (_I, [_P, _I]),
     "fhip_conv_forward_maxpool2": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V]),
     "fhip_pooling_output_dim": (_I, [_Q, _PI, _PI]),

@@ -26,7 +26,7 @@ int winograd_fused_gemm_output(const fhip_conv_param& p, int batch, float* outpu
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
-                  float* buffer, bool force_no_act, hipStream_t s);
+                  float* buffer, bool force_no_act, hipStream_t s, const float* residual = nullptr);
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch);
 int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* kernel, const float* bias,
                       hipStream_t s);
@@ -279,16 +279,17 @@ int fhip_conv_init(const fhip_conv_param* p, int algo, float* packed, const floa
 }
 
 static int conv_forward_impl(const fhip_conv_param* p, int algo, int batch, float* output, const float* input, const float* packed,
-                             float* buffer, const float* bias, void* stream, int pool)
+                             float* buffer, const float* bias, void* stream, int pool, const float* residual = nullptr)
 {
     if (!valid_param(p) || !output || !input || !packed || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (pool && (algo != FHIP_WINOGRADF63 || !winograd_can_pool(*p)))
         return fail(FHIP_E_UNSUPPORTED, "fused max pooling is available on the Winograd route with even output dims only");
+    if (residual && algo != FHIP_IM2COL) return fail(FHIP_E_UNSUPPORTED, "the fused residual add is available on the IM2COL route only");
     switch (algo)
     {
         case FHIP_NAIVE: return igemm_forward(*p, batch, output, input, packed, bias, buffer, true, s);
-        case FHIP_IM2COL: return igemm_forward(*p, batch, output, input, packed, bias, buffer, false, s);
+        case FHIP_IM2COL: return igemm_forward(*p, batch, output, input, packed, bias, buffer, false, s, residual);
         case FHIP_DEPTHWISE: return depthwise_forward(*p, batch, output, input, packed, bias, s);
         case FHIP_WINOGRADF63:
         {
@@ -368,6 +369,15 @@ int fhip_conv_forward_maxpool2(const fhip_conv_param* p, int algo, int batch, fl
 {
     return conv_forward_impl(p, algo, batch, pooled_output, input, packed, buffer, bias, stream, 1);
 }
+
+int fhip_conv_forward_residual(const fhip_conv_param* p, int algo, int batch, float* output, const float* input, const float* packed,
+                               float* buffer, const float* bias, const float* residual, void* stream)
+{
+    if (!residual) return fail(FHIP_E_BADARG, "null residual");
+    return conv_forward_impl(p, algo, batch, output, input, packed, buffer, bias, stream, 0, residual);
+}
+
+int fhip_conv_can_fuse_residual(const fhip_conv_param* p, int algo) { return valid_param(p) && algo == FHIP_IM2COL ? 1 : 0; }
 
 int fhip_conv_can_fuse_maxpool2(const fhip_conv_param* p, int algo)
 {

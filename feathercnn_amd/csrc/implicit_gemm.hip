@@ -34,6 +34,10 @@ struct ConvGemmParams
     // [s*k_tiles, (s+1)*k_tiles) and writes raw partial sums to partial[s][K][Ntot]; a reduce kernel finishes
     int split_k;
     float* partial;
+    // optional residual (same layout as out), added before the activation: out = act(conv + bias + residual);
+    // carried as a byte offset from `out` so the store path needs no second pointer table
+    int has_residual;
+    ptrdiff_t residual_delta;
 };
 
 // MODE 0: generic gather (any kernel / stride / pad)
@@ -177,6 +181,26 @@ struct ConvGemmPolicy
                 v.z += b;
                 v.w += b;
             }
+            const size_t moff = (size_t)m * p.OHW;
+            if (p.has_residual)
+            {
+                auto res = [&](const float* o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(o) + p.residual_delta); };
+                if (wide)
+                {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr[0] + moff) + p.residual_delta);
+                    v.x += r.x;
+                    v.y += r.y;
+                    v.z += r.z;
+                    v.w += r.w;
+                }
+                else
+                {
+                    if (valid & 1u) v.x += res(ptr[0] + moff);
+                    if (valid & 2u) v.y += res(ptr[1] + moff);
+                    if (valid & 4u) v.z += res(ptr[2] + moff);
+                    if (valid & 8u) v.w += res(ptr[3] + moff);
+                }
+            }
             if (p.relu)
             {
                 v.x = fmaxf(v.x, 0.f);
@@ -184,7 +208,6 @@ struct ConvGemmPolicy
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
             }
-            const size_t moff = (size_t)m * p.OHW;
             if (wide)
                 *reinterpret_cast<float4*>(ptr[0] + moff) = v;
             else
@@ -242,8 +265,8 @@ size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
 
 // finishes a split-K convolution: out[img][m][rem] = act(sum_s partial[s][m][n] + bias[m])
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
-                                                                 const float* __restrict__ bias, int K, int Ntot, int OHW, int S,
-                                                                 int has_bias, int relu)
+                                                                 const float* __restrict__ bias, const float* __restrict__ residual, int K,
+                                                                 int Ntot, int OHW, int S, int has_bias, int relu)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
@@ -253,9 +276,11 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restr
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += src[(size_t)s * stride];
     if (has_bias) v += bias[m];
-    if (relu) v = fmaxf(v, 0.f);
     const int img = n / OHW, rem = n - img * OHW;
-    out[((size_t)img * K + m) * OHW + rem] = v;
+    const size_t o = ((size_t)img * K + m) * OHW + rem;
+    if (residual) v += residual[o];
+    if (relu) v = fmaxf(v, 0.f);
+    out[o] = v;
 }
 
 // K7: Wt[q][Kp] = W[k][q], zero padded (the GPU analogue of packed_sgemm_init, avx/sgemm.cpp:312-346).
@@ -295,7 +320,7 @@ static void launch(const ConvGemmParams& g0, hipStream_t s)
 
 // force_no_act: the NAIVE algo ignores activation (avx/booster.cpp:41-61).
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
-                  float* buffer, bool force_no_act, hipStream_t s)
+                  float* buffer, bool force_no_act, hipStream_t s, const float* residual)
 {
     if (p.group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
     if (batch < 1) return fail(FHIP_E_BADARG, "batch < 1");
@@ -306,6 +331,8 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.in = in;
     g.out = out;
     g.bias = bias;
+    g.has_residual = residual != nullptr;
+    g.residual_delta = residual ? reinterpret_cast<const char*>(residual) - reinterpret_cast<const char*>(out) : 0;
     g.C = p.input_channels;
     g.K = p.output_channels;
     g.H = p.input_h;
@@ -355,8 +382,8 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     FHIP_CHECK_HIP(hipGetLastError());
     if (g.split_k > 1)
     {
-        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot, 256), g.K), dim3(256), 0, s, out, g.partial, bias, g.K, g.Ntot,
-                           g.OHW, g.split_k, g.has_bias, g.relu);
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot, 256), g.K), dim3(256), 0, s, out, g.partial, bias, residual, g.K,
+                           g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu);
         FHIP_CHECK_HIP(hipGetLastError());
     }
     return FHIP_OK;

@@ -390,6 +390,9 @@ struct ConvLayer : Layer
     bool fuse_pool = false, pool_fast = false;
     fhip_pool_param poolq;
     DeviceVec pre_pool;
+    // fusion level 2: a following Eltwise SUM (+ReLU) with an earlier blob is absorbed: top = act(conv + bias + residual)
+    Blob* residual = nullptr;
+    bool res_fast = false;
 
     ConvLayer()
     {
@@ -445,6 +448,9 @@ struct ConvLayer : Layer
         if (p.output_h < 1 || p.output_w < 1) return failf(NET_E_SHAPE, "layer %s: empty output", name.c_str());
         int rc = fhip_conv_select_algo(&p, &algo_);
         if (rc) return rc;
+        res_fast = residual && fhip_conv_can_fuse_residual(&p, algo_) != 0;
+        if (residual && (residual->n != b->n || residual->c != p.output_channels || residual->h != p.output_h || residual->w != p.output_w))
+            return failf(NET_E_SHAPE, "Shape mismatch among bottoms of layer %s.", name.c_str());
         if (fuse_pool)
         {
             poolq.channels = p.output_channels;
@@ -496,6 +502,18 @@ struct ConvLayer : Layer
     int Forward(hipStream_t s) override
     {
         const float* b = p.bias_term ? bias.d : nullptr;
+        if (residual)
+        {
+            if (residual->alias) residual->data = residual->alias->data;
+            if (res_fast)
+                return fhip_conv_forward_residual(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b,
+                                                  residual->data, s);
+            fhip_conv_param q = p; // route without the fused epilogue: conv, then the add (+ReLU) in place on the top
+            q.activation = FHIP_ACT_NONE;
+            const int rc = fhip_conv_forward(&q, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
+            if (rc) return rc;
+            return fhip_add(tops[0]->data, tops[0]->data, residual->data, tops[0]->count(), p.activation == FHIP_ACT_RELU, s);
+        }
         if (!fuse_pool) return fhip_conv_forward(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
         if (pool_fast)
             return fhip_conv_forward_maxpool2(&p, algo_, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
@@ -504,6 +522,13 @@ struct ConvLayer : Layer
         return fhip_pooling(&poolq, bottoms[0]->n, tops[0]->data, pre_pool.d, s);
     }
     int Fuse(Layer* next, int level) override;
+    // absorb `elt` = Eltwise SUM of this layer's top and `other` (a blob produced earlier in the layer list)
+    bool FuseResidual(Blob* other)
+    {
+        if (fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
+        residual = other;
+        return true;
+    }
     size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes; }
     size_t arena_bytes() const override { return buffer_bytes; }
     int algo() const override { return algo_; }
@@ -754,6 +779,7 @@ struct ScaleLayer : AffineLayer
 int ConvLayer::Fuse(Layer* next, int level)
 {
     if (fuse_pool) return 0; // nothing is absorbed behind the pooling
+    if (residual && next->type != "ReLU") return 0; // behind the residual add only its ReLU
     if (level >= 2 && next->type == "Pooling")
     {
         const fhip_pool_param& q = static_cast<PoolingLayer*>(next)->q;
@@ -1053,6 +1079,20 @@ static void fuse_layers(Net& net)
                     }
             if (uses != 1) break;
             Layer* nx = net.layers[consumer].get();
+            if (net.fusion >= 2 && nx->type == "Eltwise" && nx->bottoms.size() == 2 && nx->tops.size() == 1 && nx->bottoms[0] != nx->bottoms[1] &&
+                (cur->type == "Convolution" || cur->type == "ConvolutionDepthWise"))
+            {
+                // conv -> Eltwise(sum with an EARLIER blob) [-> ReLU]: the add moves into the conv's epilogue
+                Blob* other = nx->bottoms[0] == top ? nx->bottoms[1] : nx->bottoms[0];
+                bool earlier = false;
+                for (size_t j = 0; j < i; ++j)
+                    for (Blob* t : net.layers[j]->tops) earlier = earlier || t == other;
+                if (!earlier || !static_cast<ConvLayer*>(cur)->FuseResidual(other)) break;
+                top->fused_away = true;
+                cur->tops[0] = nx->tops[0];
+                net.layers.erase(net.layers.begin() + consumer);
+                continue;
+            }
             if (nx->bottoms.size() != 1 || nx->tops.size() != 1) break;
             if (cur->Fuse(nx, net.fusion) != 1) break;
             top->fused_away = true;

@@ -39,6 +39,14 @@ FHIP_API int fhip_conv_can_fuse_maxpool2(const fhip_conv_param* param, int algo)
 FHIP_API int fhip_conv_forward_maxpool2(const fhip_conv_param* param, int algo, int batch, float* pooled_output, const float* input,
                                         const float* packed, float* buffer, const float* bias, void* stream);
 
+/* Convolution followed by an Eltwise SUM with `residual` (same shape as the output) and the activation the param names:
+ * output = act(conv(input) + bias + residual), the add done in the GEMM epilogue (ResNet's last 1x1 of a bottleneck +
+ * shortcut + ReLU; reference: ConvLayer::Forward, EltwiseLayer::Forward -> booster::add_relu, eltwise_layer.h:69-80).  Same
+ * arguments as fhip_conv_forward plus `residual`.  IM2COL route only (fhip_conv_can_fuse_residual), else FHIP_E_UNSUPPORTED. */
+FHIP_API int fhip_conv_can_fuse_residual(const fhip_conv_param* param, int algo);
+FHIP_API int fhip_conv_forward_residual(const fhip_conv_param* param, int algo, int batch, float* output, const float* input,
+                                        const float* packed, float* buffer, const float* bias, const float* residual, void* stream);
+
 /* PoolingLayer, layers/pooling_layer.h:90-131 (fields as its LoadParam reads them). */
 typedef struct fhip_pool_param
 {

@@ -311,3 +311,62 @@ def test_fused_pool_fallback_on_odd_dims_and_non_winograd(cuda):
     assert got.shape == want["p3"].shape == (3, 12, 6, 6)
     for name in ("p0", "p1", "p2", "p3"):
         assert nerr(net.Extract(name), want[name]) <= TOL, name
+
+
+@pytest.mark.parametrize("geom", [(64, 256, 14, 1, 1, 0, 2), (256, 64, 7, 1, 1, 0, 3), (1024, 256, 7, 1, 1, 0, 2), (16, 24, 9, 3, 2, 1, 2),
+                                  (8, 12, 5, 1, 1, 0, 1)])
+def test_conv_with_fused_residual_equals_conv_then_add(cuda, geom):
+    """fhip_conv_forward_residual (add in the implicit-GEMM epilogue / in the split-K reduce) == conv, then add (+ReLU)."""
+    import ctypes
+
+    import torch
+    from feathercnn_amd import ConvLayer, ConvParam, IM2COL, _lib
+    c, k, h, ks, s, pad, n = geom
+    rng = np.random.default_rng(c + k)
+    x = rng.uniform(-1, 1, (n, c, h, h)).astype(np.float32)
+    wt = (rng.uniform(-1, 1, (k, c, ks, ks)) / np.sqrt(c * ks * ks)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+    lib = _lib.load_library()
+    for act in (0, 1):
+        plain = ConvParam.make(c, k, h, ks, s, pad, bias=True, act=0, batch=n)
+        lyr = ConvLayer(plain, _t(wt, cuda), _t(b, cuda), algo=IM2COL)
+        y = lyr.Forward(_t(x, cuda))
+        res = _t(rng.uniform(-1, 1, tuple(y.shape)).astype(np.float32), cuda)
+        want = y + res
+        if act:
+            want = torch.clamp_min(want, 0)
+        p = ConvParam.make(c, k, h, ks, s, pad, bias=True, act=act, batch=n)
+        cp = p._c()
+        assert lib.fhip_conv_can_fuse_residual(ctypes.byref(cp), IM2COL) == 1
+        out = torch.empty_like(y)
+        scratch = torch.empty(max(lyr.buffer_bytes // 4, 1), device=cuda)
+        rc = lib.fhip_conv_forward_residual(ctypes.byref(cp), IM2COL, n, out.data_ptr(), _t(x, cuda).data_ptr(), lyr.packed.data_ptr(),
+                                            scratch.data_ptr(), lyr.bias.data_ptr(), res.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), geom
+    assert lib.fhip_conv_can_fuse_residual(ctypes.byref(cp), 4) == 0
+
+
+def test_residual_fusion_in_the_net_fast_and_fallback_paths(cuda):
+    """Fusion level 2 moves conv -> Eltwise(+earlier blob) -> ReLU into the conv: implicit-GEMM epilogue where the route is
+    IM2COL, conv + in-place add where it is Winograd; a conv whose ReLU precedes the add is left alone."""
+    g = model_zoo.GraphBuilder(23)
+    x = g.input("data", 8, 12, 12)
+    a, b = g.split("s0", x)
+    y = g.conv_bn_relu("c1", a, 8, 8, 1, relu=False)           # IM2COL + BN + Scale, then the add, then ReLU
+    x = g.relu("r1", g.eltwise("e1", b, y))
+    a, b = g.split("s1", x)
+    y = g.conv("c2", a, 8, 8, 3, 1, 1)                          # Winograd: fallback path
+    x = g.relu("r2", g.eltwise("e2", y, b))
+    a, b = g.split("s2", x)
+    y = g.relu("r3a", g.conv("c3", a, 8, 8, 1))                 # ReLU BEFORE the add: must not be fused
+    x = g.eltwise("e3", b, y)
+    p, w = g.finish()
+    img = np.random.default_rng(8).uniform(-1, 1, (3, 8, 12, 12)).astype(np.float32)
+    want = netcheck.PortNet(p, w).run("data", img, "e3", keep=True)
+    net, got = _run((p, w, "data", None), img, "e3", fusion=2)
+    types = [t for t, _, _ in net.layers()]
+    assert types.count("Eltwise") == 1 and types.count("ReLU") == 0 and types.count("BatchNorm") == 0
+    for name in ("r1", "r2", "e3"):
+        assert nerr(net.Extract(name), want[name]) <= TOL, name

@@ -450,11 +450,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # FHIP_BENCH_SHARE_GPU=1 is a rehearsal switch for boxes with ONE GPU: every rank uses cuda:0 and the collectives go over
+    # gloo, so the N > 1 code path (model broadcast, barriers, max-over-ranks timing) can be exercised end to end.  Its numbers
+    # mean nothing; the driver's multi-GPU runs never set it.
+    share = os.environ.get("FHIP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_gpus = world
     env = {"dev": dev, "rank": rank, "world": world}
     step, finalize, batch = (setup_net if a.mode == "net" else setup_convstack)(a, env)

@@ -476,10 +476,18 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
             const char* e = getenv("FHIP_DW_R");
             return e ? atoi(e) : 0;
         }();
-        const int R = q.SH == 1 ? (r_env == 7 ? 7 : 4) : 2; // measured: R = 7 is 3-8 % slower than 4 except at 28x28
+        const int R = q.SH == 1 ? ((r_env == 7 || r_env == 2 || r_env == 1) ? r_env : 4) : (r_env == 1 ? 1 : 2); // measured: R = 7 is 3-8 % slower than 4 except at 28x28
         const int yblocks = ceil_div(q.OH, R), xvecs = q.OW / vx;
         const long long total = planes * yblocks * xvecs;
-        const int grid = (int)min((long long)256 * 32, (total + 255) / 256);
+        // grid-stride over at most 8192 blocks.  A plain copy is fastest with one float4 per thread and no loop
+        // (tools/copy_probe.hip: 6.2 TB/s vs 4.3-5.4 looped), but this kernel is not a plain copy: measured 1.14 ms per
+        // MobileNet step capped vs 1.21 ms with one item per lane (FHIP_DW_GRID=<blocks> changes the cap, 0 = uncapped)
+        static const long long grid_cap = [] {
+            const char* e = getenv("FHIP_DW_GRID");
+            return e ? atoll(e) : 8192LL;
+        }();
+        const long long blocks = (total + 255) / 256;
+        const int grid = (int)min(grid_cap > 0 ? grid_cap : (long long)0x7fffffff, blocks);
 #define FHIP_DW_LAUNCH(S_, VX_, R_) \
     hipLaunchKernelGGL((depthwise3x3_direct_kernel<S_, VX_, R_>), dim3(grid), dim3(256), 0, s, q, yblocks, xvecs, total)
         if (q.SH == 1)
@@ -490,12 +498,30 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
                 else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 7);
                 else FHIP_DW_LAUNCH(1, 1, 7);
             }
+            else if (R == 2)
+            {
+                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 2);
+                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 2);
+                else FHIP_DW_LAUNCH(1, 1, 2);
+            }
+            else if (R == 1)
+            {
+                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 1);
+                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 1);
+                else FHIP_DW_LAUNCH(1, 1, 1);
+            }
             else
             {
                 if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
                 else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
                 else FHIP_DW_LAUNCH(1, 1, 4);
             }
+        }
+        else if (R == 1)
+        {
+            if (vx == 4) FHIP_DW_LAUNCH(2, 4, 1);
+            else if (vx == 2) FHIP_DW_LAUNCH(2, 2, 1);
+            else FHIP_DW_LAUNCH(2, 1, 1);
         }
         else
         {

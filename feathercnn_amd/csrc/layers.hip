@@ -20,10 +20,12 @@
 namespace fhip
 {
 
+// One float4 per thread, no grid-stride loop: the fastest streaming form on this chip (tools/copy_probe.hip: 6.2 TB/s against
+// 4.3-5.4 for any looped variant).  Threads [n4, n4 + tail) finish the count % 4 (or unaligned) remainder one float each.
 __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n4, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4)
     {
         float4 v = reinterpret_cast<const float4*>(x)[i];
         v.x = fmaxf(v.x, 0.f);
@@ -31,16 +33,18 @@ __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ y, const 
         v.z = fmaxf(v.z, 0.f);
         v.w = fmaxf(v.w, 0.f);
         reinterpret_cast<float4*>(y)[i] = v;
+        return;
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = fmaxf(x[i], 0.f);
+    const size_t t = n4 * 4 + (i - n4);
+    if (t < n) y[t] = fmaxf(x[t], 0.f);
 }
 
 template <bool RELU>
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
                                                  size_t n4, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4)
     {
         const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
         float4 r = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
@@ -52,28 +56,47 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const f
             r.w = fmaxf(r.w, 0.f);
         }
         reinterpret_cast<float4*>(y)[i] = r;
+        return;
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    const size_t t = n4 * 4 + (i - n4);
+    if (t < n)
     {
-        const float r = a[i] + b[i];
-        y[i] = RELU ? fmaxf(r, 0.f) : r;
+        const float r = a[t] + b[t];
+        y[t] = RELU ? fmaxf(r, 0.f) : r;
     }
 }
 
-// y[n][c][:] = x[n][c][:] * mul[c] + add[c]  (+ ReLU); one (n, c) plane per blockIdx.x
-template <bool RELU>
+// y[n][c][:] = x[n][c][:] * mul[c] + add[c]  (+ ReLU); one float4 (VEC: HW % 4 == 0, so it stays inside a plane) or one
+// float per lane, no loop
+template <bool RELU, bool VEC>
 __global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ mul,
-                                                    const float* __restrict__ add, int C, int HW)
+                                                    const float* __restrict__ add, int C, int HW, size_t total)
 {
-    const int plane = blockIdx.x;
-    const int c = plane % C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t e = VEC ? i * 4 : i;
+    const int c = (int)((e / HW) % C);
     const float m = mul[c], a = add ? add[c] : 0.f;
-    const float* xp = x + (size_t)plane * HW;
-    float* yp = y + (size_t)plane * HW;
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < HW; i += gridDim.y * 256)
+    if (VEC)
     {
-        const float v = xp[i] * m + a;
-        yp[i] = RELU ? fmaxf(v, 0.f) : v;
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = v.x * m + a;
+        v.y = v.y * m + a;
+        v.z = v.z * m + a;
+        v.w = v.w * m + a;
+        if (RELU)
+        {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    else
+    {
+        const float v = x[i] * m + a;
+        y[i] = RELU ? fmaxf(v, 0.f) : v;
     }
 }
 
@@ -114,6 +137,24 @@ __global__ __launch_bounds__(256) void pooling_kernel(float* __restrict__ y, con
     }
 }
 
+// global pooling: one wave per (n, c) plane, lanes stride over the plane (coalesced), butterfly reduction
+template <bool AVG>
+__global__ __launch_bounds__(256) void plane_reduce_kernel(float* __restrict__ y, const float* __restrict__ x, int planes, int HW)
+{
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const float* xp = x + (size_t)plane * HW;
+    float v = AVG ? 0.f : -FLT_MAX;
+    for (int i = lane; i < HW; i += 64) v = AVG ? v + xp[i] : fmaxf(v, xp[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const float t = __shfl_xor(v, o);
+        v = AVG ? v + t : fmaxf(v, t);
+    }
+    if (lane == 0) y[plane] = AVG ? v / HW : v;
+}
+
 // one block per image: max, exp-sum, normalise over `cols` values
 __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ y, const float* __restrict__ x, int cols)
 {
@@ -149,11 +190,8 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ y, con
     for (int i = threadIdx.x; i < cols; i += 256) yp[i] = yp[i] / sum;
 }
 
-static int ew_grid(size_t n4)
-{
-    const size_t blocks = (n4 + 255) / 256;
-    return (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 16));
-}
+// threads needed: one per float4 plus one per leftover float
+static unsigned ew_grid(size_t n4, size_t n) { return (unsigned)((n4 + (n - n4 * 4) + 255) / 256); }
 
 } // namespace fhip
 
@@ -168,7 +206,7 @@ int fhip_relu(float* y, const float* x, size_t count, void* stream)
     if (count == 0) return FHIP_OK;
     const bool vec = (((uintptr_t)y | (uintptr_t)x) & 15) == 0;
     const size_t n4 = vec ? count / 4 : 0;
-    hipLaunchKernelGGL(relu_kernel, dim3(ew_grid(std::max<size_t>(n4, count / 64))), dim3(256), 0, (hipStream_t)stream, y, x, n4, count);
+    hipLaunchKernelGGL(relu_kernel, dim3(ew_grid(n4, count)), dim3(256), 0, (hipStream_t)stream, y, x, n4, count);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -179,7 +217,7 @@ int fhip_add(float* y, const float* a, const float* b, size_t count, int relu, v
     if (count == 0) return FHIP_OK;
     const bool vec = (((uintptr_t)y | (uintptr_t)a | (uintptr_t)b) & 15) == 0;
     const size_t n4 = vec ? count / 4 : 0;
-    const dim3 grid(ew_grid(std::max<size_t>(n4, count / 64)));
+    const dim3 grid(ew_grid(n4, count));
     if (relu)
         hipLaunchKernelGGL(add_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, a, b, n4, count);
     else
@@ -191,13 +229,20 @@ int fhip_add(float* y, const float* a, const float* b, size_t count, int relu, v
 int fhip_affine(float* y, const float* x, const float* mul, const float* add, int batch, int channels, int hw, int relu, void* stream)
 {
     if (!y || !x || !mul || batch < 1 || channels < 1 || hw < 1) return fail(FHIP_E_BADARG, "bad argument");
-    const long long planes = (long long)batch * channels;
-    if (planes > 0x7fffffffLL) return fail(FHIP_E_BADARG, "batch * channels too large");
-    const dim3 grid((unsigned)planes, std::max(1, std::min(ceil_div(hw, 1024), 64)));
-    if (relu)
-        hipLaunchKernelGGL(affine_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, x, mul, add, channels, hw);
+    const size_t count = (size_t)batch * channels * hw;
+    const bool vec = (hw % 4) == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0;
+    const size_t total = vec ? count / 4 : count;
+    if ((total + 255) / 256 > 0x7fffffffULL) return fail(FHIP_E_BADARG, "tensor too large");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (relu && vec)
+        hipLaunchKernelGGL((affine_kernel<true, true>), grid, dim3(256), 0, s, y, x, mul, add, channels, hw, total);
+    else if (relu)
+        hipLaunchKernelGGL((affine_kernel<true, false>), grid, dim3(256), 0, s, y, x, mul, add, channels, hw, total);
+    else if (vec)
+        hipLaunchKernelGGL((affine_kernel<false, true>), grid, dim3(256), 0, s, y, x, mul, add, channels, hw, total);
     else
-        hipLaunchKernelGGL(affine_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, x, mul, add, channels, hw);
+        hipLaunchKernelGGL((affine_kernel<false, false>), grid, dim3(256), 0, s, y, x, mul, add, channels, hw, total);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -239,7 +284,18 @@ int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const float* x, 
     q.off_x = p->pad_left + p->pad_right;
     q.average = p->pooling_type != 0;
     const long long total = (long long)q.planes * oh * ow;
-    const int grid = (int)std::min<long long>(256 * 16, (total + 255) / 256);
+    // whole-plane windows (global pooling, or a kernel covering the unpadded image): one wave per plane, coalesced
+    if (oh == 1 && ow == 1 && q.off_y == 0 && q.off_x == 0 && q.KH >= q.H && q.KW >= q.W)
+    {
+        const int planes = q.planes;
+        if (q.average)
+            hipLaunchKernelGGL(plane_reduce_kernel<true>, dim3(ceil_div(planes, 4)), dim3(256), 0, (hipStream_t)stream, y, x, planes, q.H * q.W);
+        else
+            hipLaunchKernelGGL(plane_reduce_kernel<false>, dim3(ceil_div(planes, 4)), dim3(256), 0, (hipStream_t)stream, y, x, planes, q.H * q.W);
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
+    }
+    const int grid = (int)std::min<long long>(256 * 16, (total + 255) / 256); // looped: measured faster than one output per lane here
     hipLaunchKernelGGL(pooling_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, x, q, total);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--net", default="vgg16", choices=list(DEFAULT_BATCH))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE.json config)")
+    ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (strong scaling, SURVEY.md 8d config 5: "
+                    "--net resnet50 --global-batch 512 --gpus 8); rank r takes shard_range(global, r, N) images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay per step")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: all cores, max 64)")
@@ -254,6 +256,17 @@ def make_roofline(net_name, gemm_flops, gemm_ms, dw_bytes, dw_ms):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def per_gpu_batch(a, env):
+    """Weak scaling: the configured per-GPU batch.  Strong scaling (--global-batch): this rank's shard of the total."""
+    if a.global_batch:
+        from feathercnn_amd.shard import shard_range
+        lo, hi = shard_range(a.global_batch, env["rank"], env["world"])
+        if hi - lo < 1:
+            raise SystemExit("bench: --global-batch smaller than the number of GPUs")
+        return hi - lo
+    return a.batch or DEFAULT_BATCH[a.net]
+
+
 def setup_net(a, env):
     """Whole-net mode.  -> (step, finalize)"""
     import numpy as np
@@ -262,7 +275,7 @@ def setup_net(a, env):
     from feathercnn_amd import booster, model_zoo
     from feathercnn_amd.net import Net
     dev, rank, world = env["dev"], env["rank"], env["world"]
-    batch = a.batch or DEFAULT_BATCH[a.net]
+    batch = per_gpu_batch(a, env)
     build = model_zoo.MODELS[a.net]
     # ---- model: generated on rank 0, the .bin broadcast once over RCCL (the only collective of this path) ------------
     from feathercnn_amd.shard import broadcast_model
@@ -329,7 +342,7 @@ def setup_convstack(a, env):
     from feathercnn_amd import WINOGRADF63, DEPTHWISE, IM2COL, ALGO_NAMES
     from feathercnn_amd.shard import broadcast_weights
     dev, rank, world = env["dev"], env["rank"], env["world"]
-    batch = a.batch or DEFAULT_BATCH[a.net]
+    batch = per_gpu_batch(a, env)
     layers = nets.NETS[a.net]()
 
     # ---- weights: generated on rank 0, broadcast once over RCCL (the only collective of this path) -------------------
@@ -489,7 +502,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
-    value = n_gpus * batch * a.steps / dt
+    total_images = a.global_batch if a.global_batch else n_gpus * batch
+    value = total_images * a.steps / dt
 
     # ---- per-stage / per-layer HIP-event timing (separate pass, after the timed region) -------------------------------
     extra = finalize(ms_per_step)
@@ -502,8 +516,8 @@ def main():
         res = {
             "metric": extra.pop("metric"), "value": round(value, 2), "unit": "images/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": extra.pop("workload"), "net": a.net, "mode": a.mode, "per_gpu_batch": batch, "global_batch": batch * n_gpus,
+            "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": extra.pop("workload"), "net": a.net, "mode": a.mode, "per_gpu_batch": batch, "global_batch": total_images,
                        "parallelism": f"batch-shard x{n_gpus}", "launch": extra.pop("launch")},
         }
         roofline = extra.pop("roofline", None)

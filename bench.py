@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: all cores, max 64)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
     ap.add_argument("--mode", default="net", choices=["net", "convstack"])
+    ap.add_argument("--reference-selection", action="store_true",
+                    help="route convolutions with the reference's SelectAlgo rule instead of the MI355X cost model (fhip_conv_select_algo_tuned)")
     ap.add_argument("--fusion", type=int, default=2, help="net mode: 0 none, 1 the reference's TryFuse patterns, 2 also fold BN/Scale into conv weights")
     return ap.parse_args()
 
@@ -214,7 +216,7 @@ def net_cpu_baseline(net_name, model, procs):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def winograd_and_depthwise_work(net_name, batch):
+def winograd_and_depthwise_work(net_name, batch, tuned=False):
     """Algorithmic work of the roofline kernels per step, from the conv shape list:
     tile-GEMM FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N over the layers SelectAlgo routes to WINOGRADF63, depthwise bytes
     4*(C*Hin*Win + C*Ho*Wo)*N + 40*C over the DEPTHWISE layers, direct-conv FLOPs (ConvParam::GetFLOPS) over all."""
@@ -224,7 +226,7 @@ def winograd_and_depthwise_work(net_name, batch):
     for layer in nets.NETS[net_name]():
         prm = nets.layer_param(layer, batch)
         cb = ConvBooster()
-        cb.SelectAlgo(prm)
+        cb.SelectAlgo(prm, tuned)
         direct += prm.GetFLOPS() * batch
         n_conv += 1
         if cb.algo == WINOGRADF63:
@@ -281,7 +283,7 @@ def setup_net(a, env):
     from feathercnn_amd.shard import broadcast_model
     model, t_bcast, bcast_bytes = broadcast_model(build, dev, src=0)
     p, b, in_name, out_name = model
-    net = Net(fusion=a.fusion, graph=not a.no_graph)
+    net = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection)
     net.LoadParam(p)
     net.LoadWeights(b)
     gen = torch.Generator(device=dev)
@@ -296,7 +298,7 @@ def setup_net(a, env):
 
     def finalize(ms_per_step):
         res = {"metric": "images/sec fp32 forward @224x224", "launch": "hipGraph replay per step" if not a.no_graph else "eager launches"}
-        gemm_flops, dw_bytes, direct, n_conv = winograd_and_depthwise_work(a.net, batch)
+        gemm_flops, dw_bytes, direct, n_conv = winograd_and_depthwise_work(a.net, batch, not a.reference_selection)
         layers = net.layers()
         res["workload"] = (f"{a.net} whole net ({len(netcheck_layers(p))} layers in the model file, {len(layers)} after fusion level "
                            f"{a.fusion}, {n_conv} convolutions), batch {batch} per GPU, 224x224x3, fp32, synthetic ncnn .param/.bin")
@@ -365,7 +367,7 @@ def setup_convstack(a, env):
     max_scratch, max_out = 0, 0
     for layer, (prm, w, b) in zip(layers, raw):
         name, c, k, h, ks, s, p, g = layer
-        lyr = ConvLayer(prm, w, b)
+        lyr = ConvLayer(prm, w, b, tuned=not a.reference_selection)
         x = torch.rand((batch, c, h, h), device=dev, generator=gen) * 2 - 1
         built.append((layer, prm, lyr, x))
         max_scratch = max(max_scratch, lyr.buffer_bytes)
@@ -518,7 +520,8 @@ def main():
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": extra.pop("workload"), "net": a.net, "mode": a.mode, "per_gpu_batch": batch, "global_batch": total_images,
-                       "parallelism": f"batch-shard x{n_gpus}", "launch": extra.pop("launch")},
+                       "parallelism": f"batch-shard x{n_gpus}", "launch": extra.pop("launch"),
+                       "conv_routing": "reference SelectAlgo rule" if a.reference_selection else "fhip_conv_select_algo_tuned (Winograd also on 4..8-pixel 3x3 layers)"},
         }
         roofline = extra.pop("roofline", None)
         res.update(extra)

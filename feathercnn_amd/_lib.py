@@ -43,6 +43,7 @@ SIGNATURES = {
     "fhip_conv_assign_output_dim": (_I, [_P]),
     "fhip_conv_flops": (ctypes.c_double, [_P]),
     "fhip_conv_select_algo": (_I, [_P, ctypes.POINTER(_I)]),
+    "fhip_conv_select_algo_tuned": (_I, [_P, ctypes.POINTER(_I)]),
     "fhip_conv_get_buffer_size": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "fhip_conv_init": (_I, [_P, _I, _V, _V, _V]),
     "fhip_conv_forward": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "fhip_net_set_stream": (_I, [_V, _V]),
     "fhip_net_set_fusion": (_I, [_V, _I]),
     "fhip_net_set_graph": (_I, [_V, _I]),
+    "fhip_net_set_tuned_selection": (_I, [_V, _I]),
     "fhip_net_load_param": (_I, [_V, ctypes.c_char_p]),
     "fhip_net_load_param_mem": (_I, [_V, ctypes.c_char_p, _SZ]),
     "fhip_net_load_weights": (_I, [_V, ctypes.c_char_p]),

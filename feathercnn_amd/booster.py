@@ -101,11 +101,13 @@ class ConvBooster:
     def __init__(self):
         self.algo = None
 
-    def SelectAlgo(self, param: ConvParam) -> int:
-        """avx/booster.cpp:283-310.  Returns 0, or -1 for partial groups (callers may ignore it, as ConvLayer does)."""
+    def SelectAlgo(self, param: ConvParam, tuned: bool = False) -> int:
+        """avx/booster.cpp:283-310.  Returns 0, or -1 for partial groups (callers may ignore it, as ConvLayer does).
+        tuned=True asks for the MI355X cost model instead of the reference rule (fhip_conv_select_algo_tuned)."""
         a = ctypes.c_int(-1)
         c = param._c()
-        rc = _lib.load_library().fhip_conv_select_algo(ctypes.byref(c), ctypes.byref(a))
+        lib = _lib.load_library()
+        rc = (lib.fhip_conv_select_algo_tuned if tuned else lib.fhip_conv_select_algo)(ctypes.byref(c), ctypes.byref(a))
         if rc != 0:
             self.algo = None
             return -1
@@ -156,12 +158,12 @@ class ConvLayer:
     Reshape (AssignOutputDim + SelectAlgo + GetBufferSize), Init once (packed weights replace raw weights),
     Forward per batch.  The scratch arena is handed in by the owner, like CommonMemPool (mempool.cpp:88-109)."""
 
-    def __init__(self, param: ConvParam, weight, bias=None, algo: int | None = None):
+    def __init__(self, param: ConvParam, weight, bias=None, algo: int | None = None, tuned: bool = False):
         import torch
         self.param = param
         self.param.AssignOutputDim()
         self.booster = ConvBooster()
-        rc = self.booster.SelectAlgo(param) if algo is None else self.booster.ForceSelectAlgo(algo)
+        rc = self.booster.SelectAlgo(param, tuned) if algo is None else self.booster.ForceSelectAlgo(algo)
         if rc != 0:
             raise FeatherHipError("unsupported convolution (partial group or algo)")
         self.buffer_bytes, self.packed_bytes = self.booster.GetBufferSize(param)

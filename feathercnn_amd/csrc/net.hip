@@ -348,6 +348,7 @@ struct Net
     hipStream_t stream = nullptr;
     int fusion = 1;
     bool use_graph = false;
+    bool tuned_selection = false; // fhip_conv_select_algo_tuned instead of the reference's SelectAlgo rule
     bool param_loaded = false, weights_loaded = false, fused = false, initialized = false, shapes_dirty = true;
     DeviceVec arena;
     hipGraphExec_t graph_exec = nullptr;
@@ -446,7 +447,7 @@ struct ConvLayer : Layer
             return failf(NET_E_TOPOLOGY, "convolution layer %s has %d input channels while bottom blob has %d channels", name.c_str(), p.input_channels, b->c);
         fhip_conv_assign_output_dim(&p);
         if (p.output_h < 1 || p.output_w < 1) return failf(NET_E_SHAPE, "layer %s: empty output", name.c_str());
-        int rc = fhip_conv_select_algo(&p, &algo_);
+        int rc = net->tuned_selection ? fhip_conv_select_algo_tuned(&p, &algo_) : fhip_conv_select_algo(&p, &algo_);
         if (rc) return rc;
         res_fast = residual && fhip_conv_can_fuse_residual(&p, algo_) != 0;
         if (residual && (residual->n != b->n || residual->c != p.output_channels || residual->h != p.output_h || residual->w != p.output_w))
@@ -1236,6 +1237,14 @@ int fhip_net_set_fusion(fhip_net* n, int on)
     NET_GUARD(n);
     if (n->impl.fused) return fail(FHIP_E_BADARG, "fusion already ran; set it before the first Forward");
     n->impl.fusion = on;
+    return FHIP_OK;
+}
+
+int fhip_net_set_tuned_selection(fhip_net* n, int on)
+{
+    NET_GUARD(n);
+    n->impl.tuned_selection = on != 0;
+    n->impl.shapes_dirty = true;
     return FHIP_OK;
 }
 

@@ -66,6 +66,7 @@ class Net
     int SetStream(void* hip_stream) { return fhip_net_set_stream(net_, hip_stream); }
     int SetFusion(int level) { return fhip_net_set_fusion(net_, level); }
     int SetGraph(bool on) { return fhip_net_set_graph(net_, on ? 1 : 0); }
+    int SetTunedSelection(bool on) { return fhip_net_set_tuned_selection(net_, on ? 1 : 0); }
     int LayerCount() { return fhip_net_layer_count(net_); }
     static const char* LastError() { return fhip_last_error(); }
     fhip_net* handle() { return net_; }

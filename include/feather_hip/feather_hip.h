@@ -86,6 +86,12 @@ FHIP_API double fhip_conv_flops(const fhip_conv_param* param);
 /* ConvBooster::SelectAlgo, avx/booster.cpp:283-310 (the AVX rule, incl. input_channels % 4 == 0 for Winograd).
  * Returns FHIP_E_UNSUPPORTED for partial groups, like the reference's -1. */
 FHIP_API int fhip_conv_select_algo(const fhip_conv_param* param, int* algo);
+/* The same candidates under the MI355X cost model (GPU-side addition, never the default): identical to
+ * fhip_conv_select_algo except that the reference's `input_h > 8 && input_w > 8` guard on Winograd
+ * (avx/booster.cpp:289, tuned for the CPU's cache blocking) is relaxed to `>= 4`: on this chip F(6x6,3x3) is
+ * 1.7-2.2x faster than the implicit GEMM on 3x3 stride-1 layers of 4..8 pixels (ResNet-50's 7x7 stage: 0.245 ->
+ * 0.118 ms at batch 64).  Results stay within the parity tolerance of either route. */
+FHIP_API int fhip_conv_select_algo_tuned(const fhip_conv_param* param, int* algo);
 
 /* GET_BUFFER_SIZE_FUNC, include/booster/booster.h:151; per-algo bodies avx/booster.cpp:28-33,64-71,121-128,178-197.
  * Pure and cheap (callers invoke it on every Net::Forward, src/layers/conv_layer.h:105-112).

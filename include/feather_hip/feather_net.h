@@ -81,6 +81,9 @@ FHIP_API int fhip_net_set_stream(fhip_net* net, void* stream);
 /* 1 (default): run the TryFuse pass the reference declares but never calls (layer.cpp:82-101):
  * Conv+ReLU, InnerProduct+ReLU, BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.  Set before LoadParam. */
 FHIP_API int fhip_net_set_fusion(fhip_net* net, int on);
+/* 1: convolutions choose their route with fhip_conv_select_algo_tuned (MI355X cost model) instead of the reference's
+ * SelectAlgo rule; 0 (default): the reference rule. */
+FHIP_API int fhip_net_set_tuned_selection(fhip_net* net, int on);
 /* 1: after the first Forward for a shape, record the layer sequence into a hipGraph and replay it.  Capture is not
  * allowed on the NULL stream: if no stream was set, the net creates and uses its own non-blocking stream (order device
  * inputs produced on other streams yourself). */

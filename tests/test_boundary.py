@@ -61,6 +61,22 @@ def _param(g, batch=1):
     return p
 
 
+def test_tuned_selection_differs_from_the_reference_rule_only_on_small_3x3(lib):
+    from feathercnn_amd import IM2COL, WINOGRADF63, ConvBooster
+    for g in [c[1] for c in golden_cases()] + [conv_geom(512, 512, 7, 3, 1, 1), conv_geom(256, 256, 8, 3, 1, 1), conv_geom(64, 64, 4, 3, 1, 1),
+                                               conv_geom(64, 64, 3, 3, 1, 1), conv_geom(8, 64, 7, 3, 1, 1), conv_geom(64, 66, 7, 3, 1, 1),
+                                               conv_geom(64, 64, 7, 3, 2, 1), conv_geom(64, 64, 7, 1, 1, 0), conv_geom(32, 32, 7, 3, 1, 1, group=32)]:
+        ref_rule, tuned = ConvBooster(), ConvBooster()
+        r0, r1 = ref_rule.SelectAlgo(_param(g)), tuned.SelectAlgo(_param(g), tuned=True)
+        assert r0 == r1
+        small3x3 = (g.group == 1 and g.kh == 3 and g.kw == 3 and g.sh == 1 and g.sw == 1 and min(g.ih, g.iw) >= 4 and min(g.ih, g.iw) <= 8
+                    and g.ic % 4 == 0 and g.oc % 4 == 0 and g.ic >= 16)
+        if small3x3:
+            assert (ref_rule.algo, tuned.algo) == (IM2COL, WINOGRADF63), g
+        else:
+            assert ref_rule.algo == tuned.algo, g
+
+
 def test_select_algo_and_dims_match_oracle(lib, port):
     from feathercnn_amd import ConvBooster
     geoms = [c[1] for c in golden_cases()] + [conv_geom(64, 64, 8, 3, 1, 1), conv_geom(64, 66, 56, 3, 1, 1), conv_geom(3, 64, 224, 3, 1, 1),

@@ -370,3 +370,31 @@ def test_residual_fusion_in_the_net_fast_and_fallback_paths(cuda):
     assert types.count("Eltwise") == 1 and types.count("ReLU") == 0 and types.count("BatchNorm") == 0
     for name in ("r1", "r2", "e3"):
         assert nerr(net.Extract(name), want[name]) <= TOL, name
+
+
+def test_tuned_selection_routes_small_3x3_layers_to_winograd_and_keeps_parity(cuda):
+    """fhip_conv_select_algo_tuned relaxes the reference's `h,w > 8` Winograd guard; ResNet-50's 7x7 stage then runs F(6,3).
+    Logits and probabilities still match the live reference feather::Net (which runs those layers through IM2COL)."""
+    from feathercnn_amd.net import Net
+    p, b, i, o = model_zoo.resnet50()
+    x = np.random.default_rng(12).uniform(-1, 1, (2, 3, 224, 224)).astype(np.float32)
+    outs = {}
+    for tuned in (False, True):
+        net = Net(fusion=2, tuned=tuned)
+        net.LoadParam(p)
+        net.LoadWeights(b)
+        net.FeedInput(i, x)
+        net.Forward()
+        outs[tuned] = (net.Extract("fc1000"), net.Extract(o), {n: a for _, n, a in net.layers()})
+    assert outs[False][2]["res5a_branch2b"] == "IM2COL" and outs[True][2]["res5a_branch2b"] == "WINOGRADF63"
+    assert outs[True][2]["res4a_branch2b"] == "WINOGRADF63" and outs[True][2]["conv1"] == "IM2COL"
+    if netcheck.have_ref_net():
+        ref = netcheck.RefNet(p, b)
+        want_logits, want = ref.run(i, x, "fc1000"), ref.run(i, x, o)
+        ref.close()
+    else:
+        blobs = netcheck.PortNet(p, b).run(i, x, o, keep=True)
+        want_logits, want = blobs["fc1000"], blobs[o]
+    for tuned in (False, True):
+        assert nerr(outs[tuned][0], want_logits) <= TOL, tuned
+        assert nerr(outs[tuned][1], want) <= TOL, tuned

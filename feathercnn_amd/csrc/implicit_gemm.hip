@@ -223,6 +223,8 @@ struct ConvGemmPolicy
 
 using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
+// A 64x64 tile (GemmShape<64, 64, 16, 2, 2, 8>: 4x the blocks, 8 blocks per CU) was measured against split-K on ResNet-50's
+// under-filled layers and made no difference (C1024->K256 @14 b64: 0.093 vs 0.092 ms; C256->K64 @56: 0.077 vs 0.075): not kept.
 constexpr int kConvColTile = 128;
 
 static bool conv_small_m(int K) { return K <= 64; }
@@ -245,6 +247,12 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     const long long ntot = (long long)batch * p.output_h * p.output_w;
     const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
     const int kt = kdp / kConvKTile;
+    // measurement switch: FHIP_IGEMM_SPLIT=S forces S (when it divides the k-tile count)
+    static const int forced = [] {
+        const char* e = getenv("FHIP_IGEMM_SPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return (kt % forced == 0) ? forced : 1;
     if (tiles >= 512 || kt < 16) return 1;
     // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 32 tiles x 1568) stream the weight
     // matrix once and are HBM bound: they want many more blocks in flight than the conv layers do

@@ -315,6 +315,276 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
     return FHIP_OK;
 }
 
+// ---- small-C convolutions (the first layer of every benchmark net: 3 input channels) ---------------------------------------
+// Measured against the generic gather (standalone, MI355X): VGG conv1_1 b32 0.158 vs 0.183 ms, ResNet conv1 b64 0.198 vs 0.271,
+// MobileNet conv1 b256 0.192 vs 0.276.  FHIP_SMALLC=0 disables it, FHIP_SMALLC_TW=16|32 forces the tile shape.
+// The generic gather above spends 4 scalar global loads + bounds checks per float4 of the column matrix and re-reads every
+// input pixel kh*kw times through L1.  Here a persistent block stages the whole weight matrix (C*kh*kw <= 160 rows) and, per
+// tile of 8 x 16 output pixels, the input patch ((8-1)*S+kh rows x (16-1)*S+kw columns x C) in LDS; the im2col gather then
+// happens on LDS addresses (one ds_read_b32 per MFMA B operand, offset table per reduction row).  This is the "im2col in LDS"
+// form SURVEY.md 8(a) names for K5.  Output tile = BM (32 or 64) channels x 128 pixels, 4 waves of BM x 32.
+struct SmallCParams
+{
+    const float* Wt; // packed weights [Kd16][Kp] (igemm_pack_weights_kernel), Kp >= BM
+    const float* in;
+    float* out;
+    const float* bias;
+    int C, K, H, W, OH, OW, S, PL, PT, KH, KW, Kd, Kp, N;
+    int kd2;           // MFMA k-steps: ceil(Kd / 2) rounded up to a multiple of 4 (the extra rows meet zero weights)
+    int PH, PW, patch; // patch rows, columns, floats
+    int tiles_x, tiles_y;
+    long long tiles;
+    int has_bias, relu;
+    int tw_shift; // tile = (1 << tw_shift) columns x (128 >> tw_shift) rows: 32 x 4 (a wave stores whole 128-byte lines) or 16 x 8
+};
+
+constexpr int kSmallCMaxPatch = 2816; // 11 passes of 256 lanes
+
+template <int TM, int PASSES> // PASSES * 256 >= patch floats
+__global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
+{
+    constexpr int BM = 32 * TM, EPI_LD = 36;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                                        // [2*kd2][BM]
+    float* const patch = As + (size_t)2 * q.kd2 * BM;              // [patch]
+    int* const ptab = reinterpret_cast<int*>(patch + kSmallCMaxPatch); // [patch] packed (c << 16 | r << 8 | x)
+    int* const koff = ptab + kSmallCMaxPatch;                      // [2][kd2]: koff[h*kd2 + kp] = patch offset of reduction row 2*kp + h
+    float* const scr = reinterpret_cast<float*>(koff + 2 * q.kd2) + 0; // [4][32][EPI_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    // ---- once per block: weights, reduction-row table, patch decode table
+    for (int i = tid; i < 2 * q.kd2 * (BM / 4); i += 256)
+    {
+        const int row = i / (BM / 4), c4 = i - row * (BM / 4);
+        *reinterpret_cast<float4*>(As + (size_t)row * BM + c4 * 4) = *reinterpret_cast<const float4*>(q.Wt + (size_t)row * q.Kp + c4 * 4);
+    }
+    const int KHW = q.KH * q.KW, PHW = q.PH * q.PW;
+    for (int k = tid; k < 2 * q.kd2; k += 256)
+    {
+        const int c = k / KHW, rem = k - c * KHW, u = rem / q.KW, w = rem - u * q.KW;
+        koff[(k & 1) * q.kd2 + (k >> 1)] = k < q.Kd ? c * PHW + u * q.PW + w : 0; // padded rows multiply zero weights
+    }
+    for (int e = tid; e < kSmallCMaxPatch; e += 256)
+    {
+        const int ee = min(e, q.patch - 1);
+        const int c = ee / PHW, rem = ee - c * PHW, r = rem / q.PW, x = rem - r * q.PW;
+        ptab[e] = (c << 16) | (r << 8) | x;
+    }
+    const int pix = wave * 32 + l31;
+    const int TW = 1 << q.tw_shift, TH = 128 >> q.tw_shift;
+    const int poff = (pix >> q.tw_shift) * q.S * q.PW + (pix & (TW - 1)) * q.S;
+    const size_t HW = (size_t)q.H * q.W;
+
+    // patch of tile `tt` -> registers: every load is issued unconditionally (clamped address), zeros are selected later
+    float pv[PASSES];
+    unsigned pok = 0;
+    int pck[PASSES];
+    __syncthreads(); // ptab ready
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) pck[j] = ptab[j * 256 + tid];
+    auto fetch_patch = [&](long long tt) {
+        const int tx_t = (int)(tt % q.tiles_x);
+        const long long t2 = tt / q.tiles_x;
+        const int ty_t = (int)(t2 % q.tiles_y), n = (int)(t2 / q.tiles_y);
+        const int iy0 = ty_t * TH * q.S - q.PT, ix0 = tx_t * TW * q.S - q.PL;
+        const float* img = q.in + (size_t)n * q.C * HW;
+        pok = 0;
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j)
+        {
+            const int c = pck[j] >> 16, r = (pck[j] >> 8) & 0xff, x = pck[j] & 0xff;
+            const int iy = iy0 + r, ix = ix0 + x;
+            pok |= ((unsigned)iy < (unsigned)q.H && (unsigned)ix < (unsigned)q.W) ? (1u << j) : 0u;
+            const int cy = min(max(iy, 0), q.H - 1), cx = min(max(ix, 0), q.W - 1);
+            pv[j] = img[(size_t)c * HW + (size_t)cy * q.W + cx];
+        }
+    };
+    if (blockIdx.x < q.tiles) fetch_patch(blockIdx.x);
+
+    for (long long t = blockIdx.x; t < q.tiles; t += gridDim.x)
+    {
+        const int tx_t = (int)(t % q.tiles_x);
+        const long long t2 = t / q.tiles_x;
+        const int ty_t = (int)(t2 % q.tiles_y), n = (int)(t2 / q.tiles_y);
+        const int oy0 = ty_t * TH, ox0 = tx_t * TW;
+        __syncthreads(); // every wave is done reading the previous patch
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j)
+            if (j * 256 + tid < q.patch) patch[j * 256 + tid] = (pok & (1u << j)) ? pv[j] : 0.f;
+        __syncthreads();
+        // the NEXT tile's patch is requested now, ahead of this tile's MFMAs and output stores: vmcnt retires in order and counts
+        // stores, so loads issued behind the stores would wait for the stores to drain (measured: the whole gain of this kernel)
+        fetch_patch(min(t + (long long)gridDim.x, q.tiles - 1));
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // 4 k-steps per trip: the offsets of the NEXT trip are fetched (one 16-byte LDS read) while this trip's 4 B operands,
+        // 4*TM A operands and MFMAs are in flight -- otherwise every k-step is a chain of two dependent LDS round trips
+        const float* ap = As + half * BM + l31;
+        const int4* kq = reinterpret_cast<const int4*>(koff + half * q.kd2);
+        const int groups = q.kd2 >> 2;
+        int4 ko = kq[0];
+        for (int g = 0; g < groups; ++g)
+        {
+            const int4 kn = kq[min(g + 1, groups - 1)];
+            const float b0 = patch[ko.x + poff], b1 = patch[ko.y + poff], b2 = patch[ko.z + poff], b3 = patch[ko.w + poff];
+            const float* a = ap + (size_t)(8 * g) * BM;
+            float fa[4][TM];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[u][i] = a[(size_t)(2 * u) * BM + i * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][i], b0, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][i], b1, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2][i], b2, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3][i], b3, acc[i], 0, 0, 0);
+            ko = kn;
+        }
+
+        // ---- epilogue: per-wave LDS transpose, bias + ReLU, 16-byte stores of 4 consecutive pixels of one output row
+        float* const ws = scr + wave * (32 * EPI_LD);
+        const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
+        const int p4 = wave * 32 + e_c4, oy = oy0 + (p4 >> q.tw_shift), ox = ox0 + (p4 & (TW - 1));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[i][r];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+            {
+                const int m = i * 32 + qd * 8 + e_row;
+                float4 v = *reinterpret_cast<const float4*>(&ws[(qd * 8 + e_row) * EPI_LD + e_c4]);
+                if (m < q.K && oy < q.OH && ox < q.OW)
+                {
+                    if (q.has_bias)
+                    {
+                        const float bb = q.bias[m];
+                        v.x += bb;
+                        v.y += bb;
+                        v.z += bb;
+                        v.w += bb;
+                    }
+                    if (q.relu)
+                    {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    float* o = q.out + (((size_t)n * q.K + m) * q.OH + oy) * q.OW + ox;
+                    if (ox + 3 < q.OW && (q.OW & 3) == 0)
+                        *reinterpret_cast<float4*>(o) = v;
+                    else
+                    {
+                        o[0] = v.x;
+                        if (ox + 1 < q.OW) o[1] = v.y;
+                        if (ox + 2 < q.OW) o[2] = v.z;
+                        if (ox + 3 < q.OW) o[3] = v.w;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// does the small-C kernel take this geometry?  (pure function of the param: forward and the tests agree)
+static bool smallc_applicable(const fhip_conv_param& p)
+{
+    const int s = p.stride_h > 0 ? p.stride_h : 1;
+    if (p.group != 1 || p.stride_h != p.stride_w || s > 2 || p.output_channels > 64) return false;
+    const int kd = p.input_channels * p.kernel_h * p.kernel_w;
+    const int ph = 3 * s + p.kernel_h, pw = 31 * s + p.kernel_w; // the 32 x 4 tile (the 16 x 8 one needs less)
+    static const int off = [] {
+        const char* e = getenv("FHIP_SMALLC");
+        return (e && e[0] == '0') ? 1 : 0;
+    }(); // measurement switch: FHIP_SMALLC=0 falls back to the generic gather
+    // output rows must take 16-byte stores: with scalar stores (SqueezeNet's 111-pixel rows) the generic kernel is faster
+    return !off && kd <= 160 && p.input_channels <= 8 && ph < 256 && pw < 256 && p.input_channels * ph * pw <= kSmallCMaxPatch &&
+           (p.output_w % 4) == 0;
+}
+
+static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias, bool relu,
+                          hipStream_t s)
+{
+    SmallCParams q;
+    q.Wt = packed;
+    q.in = in;
+    q.out = out;
+    q.bias = bias;
+    q.C = p.input_channels;
+    q.K = p.output_channels;
+    q.H = p.input_h;
+    q.W = p.input_w;
+    q.OH = p.output_h;
+    q.OW = p.output_w;
+    q.S = p.stride_h > 0 ? p.stride_h : 1;
+    q.PL = p.pad_left;
+    q.PT = p.pad_top;
+    q.KH = p.kernel_h;
+    q.KW = p.kernel_w;
+    q.Kd = q.C * q.KH * q.KW;
+    int kdp;
+    igemm_packed_dims(p, &kdp, &q.Kp);
+    q.N = batch;
+    q.kd2 = round_up((q.Kd + 1) / 2, 4); // 2*kd2 <= Kd rounded up to 8 <= the packed matrix's Kd16 rows (zero padded)
+    static const int tw_env = [] {
+        const char* e = getenv("FHIP_SMALLC_TW");
+        return e ? atoi(e) : 0;
+    }();
+    // 32 x 4 tiles when they divide the row (a wave then stores whole 128-byte lines: VGG conv1_1 0.158 vs 0.180 ms), else 16 x 8
+    // (no wasted columns on 112-pixel rows: ResNet conv1 0.198 vs 0.223 ms)
+    q.tw_shift = tw_env == 16 ? 4 : (tw_env == 32 ? 5 : ((q.OW % 32) == 0 ? 5 : 4));
+    const int tw = 1 << q.tw_shift, th = 128 >> q.tw_shift;
+    q.PH = (th - 1) * q.S + q.KH;
+    q.PW = (tw - 1) * q.S + q.KW;
+    q.patch = q.C * q.PH * q.PW;
+    q.tiles_x = ceil_div(q.OW, tw);
+    q.tiles_y = ceil_div(q.OH, th);
+    q.tiles = (long long)batch * q.tiles_x * q.tiles_y;
+    q.has_bias = p.bias_term != 0;
+    q.relu = relu;
+    const int tm = q.K <= 32 ? 1 : 2, bm = 32 * tm;
+    const size_t lds = ((size_t)2 * q.kd2 * bm + kSmallCMaxPatch + 4 * 32 * 36) * sizeof(float) + ((size_t)kSmallCMaxPatch + 2 * q.kd2) * sizeof(int);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+    const int grid = (int)std::min<long long>(q.tiles, (long long)device_compute_units() * per_cu);
+    const int passes = ceil_div(q.patch, 256);
+#define FHIP_SMALLC_LAUNCH(TM_, P_)                                                                                               \
+    do                                                                                                                            \
+    {                                                                                                                             \
+        static bool attr_set = false; /* dynamic LDS above 64 KB must be allowed once per kernel */                                \
+        if (!attr_set)                                                                                                            \
+        {                                                                                                                         \
+            FHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<TM_, P_>),                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                          \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv_smallc_kernel<TM_, P_>), dim3(grid), dim3(256), lds, s, q);                                      \
+    } while (0)
+    if (tm == 1)
+    {
+        if (passes <= 3) FHIP_SMALLC_LAUNCH(1, 3);
+        else if (passes <= 7) FHIP_SMALLC_LAUNCH(1, 7);
+        else FHIP_SMALLC_LAUNCH(1, 11);
+    }
+    else
+    {
+        if (passes <= 3) FHIP_SMALLC_LAUNCH(2, 3);
+        else if (passes <= 7) FHIP_SMALLC_LAUNCH(2, 7);
+        else FHIP_SMALLC_LAUNCH(2, 11);
+    }
+#undef FHIP_SMALLC_LAUNCH
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
 template <class Shape, int MODE>
 static void launch(const ConvGemmParams& g0, hipStream_t s)
 {
@@ -364,6 +634,11 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.Ntot = (int)ntot;
     g.has_bias = p.bias_term != 0;
     g.relu = (p.activation == FHIP_ACT_RELU) && !force_no_act;
+    if (!residual && smallc_applicable(p))
+    {
+        StageTimer tm(FHIP_STAGE_IGEMM, s);
+        return smallc_forward(p, batch, out, in, packed, bias, g.relu, s);
+    }
     g.split_k = igemm_split(p, batch);
     if (g.split_k > 1 && !buffer) return fail(FHIP_E_BADARG, "this geometry runs split-K and needs the scratch buffer GetBufferSize asked for");
     g.partial = buffer;

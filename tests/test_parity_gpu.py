@@ -364,7 +364,8 @@ dev = torch.device("cuda:0")
 worst = 0.0
 # NB (24, 36): the REAL reference segfaults on ragged tiles when input_channels % 8 == 4 (e.g. 20->36 @19x19; probe in DESIGN.md)
 for g, n in [(conv_geom(24, 36, 19, 3, 1, 1), 5), (conv_geom(64, 64, 30, 3, 1, 1), 3), (conv_geom(16, 16, 28, 3, 1, 1, group=16), 3),
-             (conv_geom(16, 16, 28, 3, 2, 1, group=16), 3)]:
+             (conv_geom(16, 16, 28, 3, 2, 1, group=16), 3), (conv_geom(3, 24, 40, 7, 2, 3), 3), (conv_geom(3, 64, 36, 3, 1, 1, w=64), 2),
+             (conv_geom(4, 32, 33, 3, 2, 1, w=24), 2), (conv_geom(512, 64, 7, 1, 1, 0), 4)]:
     x, w, b = synth(g, n, seed=4)
     p = ConvParam(output_channels=g.oc, input_channels=g.ic, input_h=g.ih, input_w=g.iw, kernel_h=g.kh, kernel_w=g.kw, stride_h=g.sh,
                   stride_w=g.sw, pad_left=g.pl, pad_right=g.pr, pad_top=g.pt, pad_bottom=g.pb, group=g.group, bias_term=True, activation=1, batch=n)
@@ -377,10 +378,12 @@ assert worst <= 1e-4
 
 
 @pytest.mark.parametrize("env", [{"FHIP_WINO_FUSED": "1"}, {"FHIP_WINO_OVERLAP": "2"}, {"FHIP_WINO_OVERLAP": "3"}, {"FHIP_DW_PATH": "lds"},
-                                 {"FHIP_DW_R": "7"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+                                 {"FHIP_DW_R": "7"}, {"FHIP_DW_R": "2", "FHIP_DW_GRID": "0"}, {"FHIP_SMALLC": "0"}, {"FHIP_SMALLC_TW": "16"},
+                                 {"FHIP_SMALLC_TW": "32"}, {"FHIP_IGEMM_SPLIT": "4"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_measurement_switch_paths_stay_correct(env, cuda, tmp_path):
     """The alternative kernels kept behind environment switches (fused Winograd GEMM+output, two-stream sub-batch pipeline,
-    LDS-staged depthwise, 7-row depthwise patches) are slower, not wrong: each is read once per process, so each runs in its own."""
+    LDS-staged depthwise, other depthwise patch heights / uncapped grid, generic gather instead of the small-C kernel and its two tile
+    shapes, forced split-K) are slower, not wrong: each is read once per process, so each runs in its own."""
     import os
     import subprocess
     import sys

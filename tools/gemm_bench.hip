@@ -8,6 +8,7 @@
 #include "gemm_core.h"
 #include "wino_gemm_policy.h"
 #include "gemm_core_v0.h"
+#include "gemm_core_p3.h"
 
 using namespace fhip;
 namespace fhip
@@ -35,13 +36,14 @@ struct Case
 };
 
 static int g_cus = 256;
+static int g_batches = 64;
 static long long* g_prof = nullptr;
 
-template <class Shape, int ABLATE, bool V0 = false>
+template <class Shape, int ABLATE, int V0 = 0>
 double run(const char* name, const Case& cs, float* U, float* V, float* M, int reps)
 {
     WinoGemmPolicy::Params g;
-    g.batches = 64;
+    g.batches = g_batches;
     g.U = U;
     g.V = V;
     g.M = M;
@@ -56,8 +58,10 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     const int tiles = g.batches * g.m_tiles * g.n_tiles;
     dim3 grid(tiles);
     auto launch = [&]() {
-        if constexpr (V0)
+        if constexpr (V0 == 1)
             hipLaunchKernelGGL((gemm_mfma_kernel_v0<Shape, WinoGemmPolicy, ABLATE, 2>), grid, dim3(Shape::THREADS), 0, 0, g);
+        else if constexpr (V0 == 2)
+            hipLaunchKernelGGL((gemm_mfma_kernel_p3<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
         else
             hipLaunchKernelGGL((gemm_mfma_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
     };
@@ -73,7 +77,7 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     float ms = 0;
     CK(hipEventElapsedTime(&ms, a, b));
     ms /= reps;
-    const double tf = 2.0 * 64 * cs.K * cs.C * (double)cs.P / ms / 1e9;
+    const double tf = 2.0 * g_batches * cs.K * cs.C * (double)cs.P / ms / 1e9;
     printf("  %-34s C%4d K%4d P%6d grid %6d  %8.4f ms  %7.2f TF (%.1f%% of 157.3)\n", name, cs.C, cs.K, cs.P, grid.x, ms, tf, tf / 157.3 * 100);
     return tf;
 }
@@ -100,13 +104,33 @@ int main(int argc, char** argv)
     for (size_t off = 0; off < maxV; off += h.size()) CK(hipMemcpy(V + off, h.data(), std::min(h.size(), maxV - off) * 4, hipMemcpyHostToDevice));
     hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, 0);
     printf("CUs %d\n", g_cus);
+    if (argc > 2)
+    {
+        // occupancy scan: ONE 128x64 tile per block, `bpc` blocks per CU resident at once, deep K: what does the main loop reach
+        // when only 1, 2, 3, 4 blocks share a CU?  (ablations: 1 = no global fetch, 2 = no store)
+        g_batches = 1;
+        for (int kt : {64, 256})
+            for (int bpc : {1, 2, 3, 4, 8})
+            {
+                Case c{kt * 16, 128, 64 * g_cus * bpc};
+                if ((size_t)c.C * round_up(c.P, 256) > maxV || (size_t)c.K * round_up(c.P, 256) > maxM) continue;
+                printf("kt %d, %d block(s) per CU\n", kt, bpc);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("product", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 2>("p3", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 1>("no global fetch", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 1, 2>("p3 no global fetch", c, U, V, M, reps);
+            }
+        return 0;
+    }
     for (auto& c : cases)
     {
         printf("case C=%d K=%d P=%d\n", c.C, c.K, c.P);
         for (int round = 0; round < 3; ++round)
         {
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("128x64x16 2x2 (product)", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 2>("128x64x16 2x2 p3", c, U, V, M, reps);
             run<GemmShape<64, 128, 16, 1, 4, 4>, 0>("64x128x16 1x4 (small-M)", c, U, V, M, reps);
+            run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 2>("64x128x16 1x4 p3", c, U, V, M, reps);
         }
     }
     return 0;

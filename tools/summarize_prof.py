@@ -46,6 +46,29 @@ def main(d):
             print(f"| `{k}` | " + " | ".join(f"{agg[k][c][0] / max(agg[k][c][1], 1):.4g}" if c in agg[k] else "" for c in counters) + " |")
 
 
+    # derived per-kernel figures: HBM rate from the PMC bytes over the kernel-trace average duration, MFMA utilisation and
+    # effective clock from the SQ / GRBM counters (MI355X: 8 XCDs -> GRBM_GUI_ACTIVE / 8 = busy cycles of the dispatch;
+    # 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs)
+    if agg and stats:
+        dur = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+        print("\n## derived per kernel (PMC passes run the same command with --steps 2, so averages are per dispatch)\n")
+        print("| kernel | avg us (trace) | HBM bytes / dispatch (2*FETCH + WRITE) | HBM GB/s | frac of 8 TB/s | MFMA util (busy SIMD-cycles / 1024 / cycles) |")
+        print("|---|---|---|---|---|---|")
+        for k in sorted(agg, key=lambda k: -dur.get(k, 0) * agg[k].get("FETCH_SIZE", [0, 0])[1]):
+            if k not in dur or "FETCH_SIZE" not in agg[k] or "WRITE_SIZE" not in agg[k]:
+                continue
+            f = agg[k]["FETCH_SIZE"][0] / max(agg[k]["FETCH_SIZE"][1], 1)
+            w = agg[k]["WRITE_SIZE"][0] / max(agg[k]["WRITE_SIZE"][1], 1)
+            by = (2.0 * f + w) * 1024.0
+            us = dur[k] / 1e3
+            gbs = by / (us * 1e-6) / 1e9 if us > 0 else 0
+            cyc = agg[k]["GRBM_GUI_ACTIVE"][0] / max(agg[k]["GRBM_GUI_ACTIVE"][1], 1) / 8.0 if "GRBM_GUI_ACTIVE" in agg[k] else 0
+            mf = agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0] / max(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1], 1) if "SQ_VALU_MFMA_BUSY_CYCLES" in agg[k] else 0
+            util = mf / 1024.0 / cyc if cyc > 0 else 0
+            if us < 3:
+                continue
+            print(f"| `{k}` | {us:.1f} | {by / 1e6:.1f} MB | {gbs:.0f} | {gbs / 8000:.3f} | {util:.3f} |")
+
     # machine-readable digest for bench.py's roofline.traffic: HBM bytes per launch of the hot kernels.
     # MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
     # stream, so the read side is doubled; WRITE_SIZE is taken as reported; both are KiB.

@@ -26,7 +26,9 @@ struct ConvGemmParams
     const float* bias;
     int C, K, H, W, OH, OW, SH, SW, PL, PT, KH, KW;
     int Kd;   // C*KH*KW
-    int Kp;   // padded output channels = row stride of Wt
+    int Kp;   // padded output channels
+    int Kdp;  // padded reduction length (rows of a weight panel)
+    int bm;   // rows per weight panel = the kernel's BM: Wt is [Kp / bm panels][Kdp][bm]
     int Ntot; // N*OH*OW
     int OHW, HW, KHW;
     int has_bias, relu;
@@ -51,10 +53,15 @@ struct ConvGemmPolicy
     struct ALoad
     {
         const float* base;
-        __device__ ALoad(const Params& p, int split, int m4) : base(p.Wt + (size_t)split * p.k_tiles * kConvKTile * p.Kp + m4) {}
+        // panel-major weights: the rows a block streams are ONE contiguous run of memory (k-tile after k-tile), which is what
+        // the InnerProduct shapes need from HBM (VGG fc6: 32 panels of 12.8 MB, each read once by the blocks of one panel)
+        __device__ ALoad(const Params& p, int split, int m4)
+            : base(p.Wt + ((size_t)(m4 / p.bm) * p.Kdp + (size_t)split * p.k_tiles * kConvKTile) * p.bm + (m4 % p.bm))
+        {
+        }
         __device__ float4 load(const Params& p, int krow) const
         {
-            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.Kp); // Wt zero padded in both dims
+            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.bm); // Wt zero padded in both dims
         }
     };
 
@@ -228,6 +235,11 @@ using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
 constexpr int kConvColTile = 128;
 
 static bool conv_small_m(int K) { return K <= 64; }
+// InnerProduct at small batch: with N <= 32 columns a 64-column tile spends half its MFMAs on padding, and fp32 MFMA is slow
+// enough that this bounds the rate the weight matrix can be streamed at (128x64 tile: 8 B of weights per clk per CU = 4.5 TB/s
+// at best).  A 64x32 tile of two waves doubles that bound.
+using ConvShapeNarrow = GemmShape<64, 32, 16, 2, 1, 8>;
+static bool conv_narrow_n(long long ntot) { return ntot <= 32; }
 
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
 {
@@ -243,8 +255,9 @@ static int igemm_split(const fhip_conv_param& p, int batch)
 {
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
-    const int bm = conv_small_m(p.output_channels) ? 64 : 128, bn = conv_small_m(p.output_channels) ? 128 : 64;
     const long long ntot = (long long)batch * p.output_h * p.output_w;
+    const bool narrow = conv_narrow_n(ntot);
+    const int bm = (narrow || conv_small_m(p.output_channels)) ? 64 : 128, bn = narrow ? 32 : (conv_small_m(p.output_channels) ? 128 : 64);
     const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
     const int kt = kdp / kConvKTile;
     // measurement switch: FHIP_IGEMM_SPLIT=S forces S (when it divides the k-tile count)
@@ -257,7 +270,7 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 32 tiles x 1568) stream the weight
     // matrix once and are HBM bound: they want many more blocks in flight than the conv layers do
     const bool deep = kt >= 512;
-    const int want = (int)std::min<long long>(deep ? 32 : 8, ((deep ? 2048 : 768) + tiles - 1) / tiles);
+    const int want = (int)std::min<long long>(deep ? 32 : 8, ((deep ? 1024 : 768) + tiles - 1) / tiles); // fc6: 64 tiles x 16 (measured best of 8..98)
     int best = 1;
     for (int s = 2; s <= want; ++s)
         if (kt % s == 0 && kt / s >= 8) best = s;
@@ -291,13 +304,14 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restr
     out[o] = v;
 }
 
-// K7: Wt[q][Kp] = W[k][q], zero padded (the GPU analogue of packed_sgemm_init, avx/sgemm.cpp:312-346).
+// K7: Wt[k / bm][q][k % bm] = W[k][q], zero padded: panels of bm output channels, reduction index next, channel fastest
+// (the GPU analogue of packed_sgemm_init's row panels, avx/sgemm.cpp:312-346).
 __global__ __launch_bounds__(256) void igemm_pack_weights_kernel(float* __restrict__ Wt, const float* __restrict__ w, int K,
-                                                                int Kd, int Kp)
+                                                                int Kd, int Kdp, int bm)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;
-    if (k < K) Wt[(size_t)q * Kp + k] = w[(size_t)k * Kd + q];
+    if (k >= K) return;
+    for (int q = blockIdx.y; q < Kd; q += gridDim.y) Wt[((size_t)(k / bm) * Kdp + q) * bm + (k % bm)] = w[(size_t)k * Kd + q];
 }
 
 int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s)
@@ -306,11 +320,10 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
     const int Kd = p.input_channels * p.kernel_h * p.kernel_w;
-    if (Kd > 65535) return fail(FHIP_E_BADARG, "C*kh*kw too large");
     StageTimer tm(FHIP_STAGE_INIT, s);
     FHIP_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)kdp * kp * sizeof(float), s));
-    hipLaunchKernelGGL(igemm_pack_weights_kernel, dim3(ceil_div(p.output_channels, 256), Kd), dim3(256), 0, s, packed, kernel,
-                       p.output_channels, Kd, kp);
+    hipLaunchKernelGGL(igemm_pack_weights_kernel, dim3(ceil_div(p.output_channels, 256), std::min(Kd, 65535)), dim3(256), 0, s, packed, kernel,
+                       p.output_channels, Kd, kdp, conv_small_m(p.output_channels) ? 64 : 128);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -325,7 +338,7 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
 // form SURVEY.md 8(a) names for K5.  Output tile = BM (32 or 64) channels x 128 pixels, 4 waves of BM x 32.
 struct SmallCParams
 {
-    const float* Wt; // packed weights [Kd16][Kp] (igemm_pack_weights_kernel), Kp >= BM
+    const float* Wt; // packed weights: K <= 64 means ONE panel [Kd16][64] (igemm_pack_weights_kernel)
     const float* in;
     float* out;
     const float* bias;
@@ -626,6 +639,8 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.Kd = g.C * g.KH * g.KW;
     int kdp;
     igemm_packed_dims(p, &kdp, &g.Kp);
+    g.Kdp = kdp;
+    g.bm = conv_small_m(g.K) ? 64 : 128; // panel height the weights were packed with (igemm_init)
     g.OHW = g.OH * g.OW;
     g.HW = g.H * g.W;
     g.KHW = g.KH * g.KW;
@@ -650,7 +665,13 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     if (one) mode = (g.SH == 1 && g.SW == 1 && (g.OHW % 4) == 0) ? 2 : 1;
     const bool small = conv_small_m(g.K);
     StageTimer tm(FHIP_STAGE_IGEMM, s);
-    if (small)
+    if (conv_narrow_n(ntot))
+    {
+        if (mode == 2) launch<ConvShapeNarrow, 2>(g, s);
+        else if (mode == 1) launch<ConvShapeNarrow, 1>(g, s);
+        else launch<ConvShapeNarrow, 0>(g, s);
+    }
+    else if (small)
     {
         if (mode == 2) launch<ConvShapeSmallM, 2>(g, s);
         else if (mode == 1) launch<ConvShapeSmallM, 1>(g, s);

@@ -137,6 +137,43 @@ __global__ __launch_bounds__(256) void pooling_kernel(float* __restrict__ y, con
     }
 }
 
+// 3x3 / stride 2 / unpadded MAX pooling (ResNet pool1, SqueezeNet): 4 consecutive outputs per lane from 3 rows of 9 inputs, read as
+// two 16-byte vectors + one scalar per row (the generic kernel issues 36 scalar loads for the same 4 outputs).  Needs W % 4 == 0
+// (aligned vectors); the clipped last window of ceil mode is handled by the column / row guards.
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(float* __restrict__ y, const float* __restrict__ x, int planes, int H, int W, int OH,
+                                                        int OW, int ow4, long long total)
+{
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+    {
+        const int xq = (int)(idx % ow4);
+        const long long t = idx / ow4;
+        const int oy = (int)(t % OH);
+        const long long plane = t / OH;
+        const int ox = xq * 4, ix = ox * 2;
+        const float* xp = x + plane * H * W;
+        float m0 = -FLT_MAX, m1 = -FLT_MAX, m2 = -FLT_MAX, m3 = -FLT_MAX;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+        {
+            const int iy = oy * 2 + r;
+            if (iy >= H) break;
+            const float* row = xp + (size_t)iy * W + ix;
+            const float4 a = *reinterpret_cast<const float4*>(row);                                  // ix + 3 < W always (W % 4 == 0)
+            const float4 b = ix + 4 < W ? *reinterpret_cast<const float4*>(row + 4) : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+            const float c = ix + 8 < W ? row[8] : -FLT_MAX;
+            m0 = fmaxf(m0, fmaxf(fmaxf(a.x, a.y), a.z));
+            m1 = fmaxf(m1, fmaxf(fmaxf(a.z, a.w), b.x));
+            m2 = fmaxf(m2, fmaxf(fmaxf(b.x, b.y), b.z));
+            m3 = fmaxf(m3, fmaxf(fmaxf(b.z, b.w), c));
+        }
+        float* yp = y + (plane * OH + oy) * OW + ox;
+        yp[0] = m0;
+        if (ox + 1 < OW) yp[1] = m1;
+        if (ox + 2 < OW) yp[2] = m2;
+        if (ox + 3 < OW) yp[3] = m3;
+    }
+}
+
 // global pooling: one wave per (n, c) plane, lanes stride over the plane (coalesced), butterfly reduction
 template <bool AVG>
 __global__ __launch_bounds__(256) void plane_reduce_kernel(float* __restrict__ y, const float* __restrict__ x, int planes, int HW)
@@ -292,6 +329,16 @@ int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const float* x, 
             hipLaunchKernelGGL(plane_reduce_kernel<true>, dim3(ceil_div(planes, 4)), dim3(256), 0, (hipStream_t)stream, y, x, planes, q.H * q.W);
         else
             hipLaunchKernelGGL(plane_reduce_kernel<false>, dim3(ceil_div(planes, 4)), dim3(256), 0, (hipStream_t)stream, y, x, planes, q.H * q.W);
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
+    }
+    if (!q.average && q.KH == 3 && q.KW == 3 && q.SH == 2 && q.SW == 2 && q.off_y == 0 && q.off_x == 0 && (q.W % 4) == 0 &&
+        (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    {
+        const int ow4 = ceil_div(ow, 4);
+        const long long items = (long long)q.planes * oh * ow4;
+        hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)std::min<long long>(256 * 32, (items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y,
+                           x, q.planes, q.H, q.W, oh, ow, ow4, items);
         FHIP_CHECK_HIP(hipGetLastError());
         return FHIP_OK;
     }

@@ -53,7 +53,9 @@ def test_affine_matches_reference_formula(cuda, shape):
 POOLS = [  # (c, h, w, kernel, stride, (pl, pr, pt, pb), type, global)
     (3, 8, 8, 2, 2, (0, 0, 0, 0), 0, False), (4, 112, 112, 3, 2, (0, 0, 0, 0), 0, False), (5, 13, 11, 3, 2, (1, 1, 1, 1), 0, False),
     (2, 10, 10, 3, 1, (1, 1, 1, 1), 1, False), (3, 9, 7, (3, 2), (1, 2), (0, 0, 1, 0), 1, False), (6, 7, 7, 7, 1, (0, 0, 0, 0), 1, True),
-    (2, 5, 9, 1, 1, (0, 0, 0, 0), 0, True), (2, 6, 6, 2, 2, (1, 0, 0, 1), 1, False)]
+    (2, 5, 9, 1, 1, (0, 0, 0, 0), 0, True), (2, 6, 6, 2, 2, (1, 0, 0, 1), 1, False),
+    (3, 12, 12, 3, 2, (0, 0, 0, 0), 0, False), (2, 13, 16, 3, 2, (0, 0, 0, 0), 0, False), (2, 7, 4, 3, 2, (0, 0, 0, 0), 0, False),   # 3x3/s2 fast path
+    (2, 9, 20, 3, 2, (0, 0, 0, 0), 0, False), (2, 3, 8, 3, 2, (0, 0, 0, 0), 0, False), (2, 15, 15, 3, 2, (0, 0, 0, 0), 0, False)]
 
 
 @pytest.mark.parametrize("case", POOLS)

@@ -16,7 +16,7 @@ from feathercnn_amd.net import Net  # noqa: E402
 def run(name, batch, fusion, steps=10):
     t0 = time.time()
     p, b, i, o = model_zoo.MODELS[name]()
-    net = Net(fusion=fusion, graph=False)
+    net = Net(fusion=fusion, graph=False, tuned=True)
     net.LoadParam(p)
     net.LoadWeights(b)
     del b
@@ -46,7 +46,7 @@ def run(name, batch, fusion, steps=10):
     worst = sorted(timed, key=lambda r: -r[3])[:8]
     print("   slowest:", ", ".join(f"{nm}({typ[:4]}) {ms:.3f}" for typ, nm, algo, ms in worst))
     net.close()
-    net = Net(fusion=fusion, graph=True)
+    net = Net(fusion=fusion, graph=True, tuned=True)
     net.LoadParam(p)
     net.LoadWeights(model_zoo.MODELS[name]()[1])
     net.FeedInput(i, x)

@@ -203,7 +203,7 @@ int fhip_conv_select_algo_tuned(const fhip_conv_param* p, int* algo)
     const int rc = fhip_conv_select_algo(p, algo);
     if (rc) return rc;
     if (*algo == FHIP_IM2COL && p->group == 1 && p->kernel_h == 3 && p->kernel_w == 3 && p->stride_h == 1 && p->stride_w == 1 && p->input_h >= 4 &&
-        p->input_w >= 4 && p->output_channels % 4 == 0 && p->input_channels % 4 == 0 && p->input_channels >= 16)
+        p->input_w >= 4 && p->output_channels % 4 == 0 && p->input_channels % 4 == 0 && p->input_channels >= 16 && p->input_channels <= 1024)
         *algo = FHIP_WINOGRADF63;
     return FHIP_OK;
 }

@@ -90,7 +90,8 @@ FHIP_API int fhip_conv_select_algo(const fhip_conv_param* param, int* algo);
  * fhip_conv_select_algo except that the reference's `input_h > 8 && input_w > 8` guard on Winograd
  * (avx/booster.cpp:289, tuned for the CPU's cache blocking) is relaxed to `>= 4`: on this chip F(6x6,3x3) is
  * 1.7-2.2x faster than the implicit GEMM on 3x3 stride-1 layers of 4..8 pixels (ResNet-50's 7x7 stage: 0.245 ->
- * 0.118 ms at batch 64).  Results stay within the parity tolerance of either route. */
+ * 0.118 ms at batch 64).  Limited to 16 <= input_channels <= 1024: F(6,3)'s fp32 error grows with the reduction length
+ * (4e-5 normalised at C = 1024 against the reference's IM2COL result; the bar is 1e-4). */
 FHIP_API int fhip_conv_select_algo_tuned(const fhip_conv_param* param, int* algo);
 
 /* GET_BUFFER_SIZE_FUNC, include/booster/booster.h:151; per-algo bodies avx/booster.cpp:28-33,64-71,121-128,178-197.

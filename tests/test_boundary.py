@@ -65,12 +65,12 @@ def test_tuned_selection_differs_from_the_reference_rule_only_on_small_3x3(lib):
     from feathercnn_amd import IM2COL, WINOGRADF63, ConvBooster
     for g in [c[1] for c in golden_cases()] + [conv_geom(512, 512, 7, 3, 1, 1), conv_geom(256, 256, 8, 3, 1, 1), conv_geom(64, 64, 4, 3, 1, 1),
                                                conv_geom(64, 64, 3, 3, 1, 1), conv_geom(8, 64, 7, 3, 1, 1), conv_geom(64, 66, 7, 3, 1, 1),
-                                               conv_geom(64, 64, 7, 3, 2, 1), conv_geom(64, 64, 7, 1, 1, 0), conv_geom(32, 32, 7, 3, 1, 1, group=32)]:
+                                               conv_geom(64, 64, 7, 3, 2, 1), conv_geom(64, 64, 7, 1, 1, 0), conv_geom(32, 32, 7, 3, 1, 1, group=32), conv_geom(1024, 64, 7, 3, 1, 1), conv_geom(1028, 64, 7, 3, 1, 1)]:
         ref_rule, tuned = ConvBooster(), ConvBooster()
         r0, r1 = ref_rule.SelectAlgo(_param(g)), tuned.SelectAlgo(_param(g), tuned=True)
         assert r0 == r1
         small3x3 = (g.group == 1 and g.kh == 3 and g.kw == 3 and g.sh == 1 and g.sw == 1 and min(g.ih, g.iw) >= 4 and min(g.ih, g.iw) <= 8
-                    and g.ic % 4 == 0 and g.oc % 4 == 0 and g.ic >= 16)
+                    and g.ic % 4 == 0 and g.oc % 4 == 0 and 16 <= g.ic <= 1024)
         if small3x3:
             assert (ref_rule.algo, tuned.algo) == (IM2COL, WINOGRADF63), g
         else:

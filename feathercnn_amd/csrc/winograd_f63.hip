@@ -17,6 +17,7 @@
 // instead of a padded copy of the input.
 #include "gemm_core.h"
 #include "wino_gemm_policy.h"
+#include "wino_gemm_glds.h"
 
 namespace fhip
 {
@@ -459,8 +460,15 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     {
         g.m_tiles = g.Kp / WinoShapeBig::BM;
         g.n_tiles = ceil_div(pl.columns, WinoShapeBig::BN);
-        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
-                           dim3(WinoShapeBig::THREADS), 0, s, g);
+        static const int glds_off = [] {
+            const char* e = getenv("FHIP_WINO_GLDS");
+            return (e && e[0] == '0') ? 1 : 0;
+        }(); // measurement switch: FHIP_WINO_GLDS=0 runs the register-staged main loop of gemm_core.h
+        if (!glds_off)
+            hipLaunchKernelGGL(wino_gemm_glds_kernel<2>, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                               dim3(WinoShapeBig::THREADS), 0, s, g);
     }
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;

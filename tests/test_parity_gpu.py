@@ -379,7 +379,7 @@ assert worst <= 1e-4
 
 @pytest.mark.parametrize("env", [{"FHIP_WINO_FUSED": "1"}, {"FHIP_WINO_OVERLAP": "2"}, {"FHIP_WINO_OVERLAP": "3"}, {"FHIP_DW_PATH": "lds"},
                                  {"FHIP_DW_R": "7"}, {"FHIP_DW_R": "2", "FHIP_DW_GRID": "0"}, {"FHIP_SMALLC": "0"}, {"FHIP_SMALLC_TW": "16"},
-                                 {"FHIP_SMALLC_TW": "32"}, {"FHIP_IGEMM_SPLIT": "4"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+                                 {"FHIP_SMALLC_TW": "32"}, {"FHIP_IGEMM_SPLIT": "4"}, {"FHIP_WINO_GLDS": "0"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_measurement_switch_paths_stay_correct(env, cuda, tmp_path):
     """The alternative kernels kept behind environment switches (fused Winograd GEMM+output, two-stream sub-batch pipeline,
     LDS-staged depthwise, other depthwise patch heights / uncapped grid, generic gather instead of the small-C kernel and its two tile

@@ -4,11 +4,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
+#include <algorithm>
 
 #include "gemm_core.h"
 #include "wino_gemm_policy.h"
 #include "gemm_core_v0.h"
 #include "gemm_core_p3.h"
+#include "wino_gemm_glds.h"
 
 using namespace fhip;
 namespace fhip
@@ -37,6 +40,7 @@ struct Case
 
 static int g_cus = 256;
 static int g_batches = 64;
+static int g_ref_pp = 0;
 static long long* g_prof = nullptr;
 
 template <class Shape, int ABLATE, int V0 = 0>
@@ -60,6 +64,10 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     auto launch = [&]() {
         if constexpr (V0 == 1)
             hipLaunchKernelGGL((gemm_mfma_kernel_v0<Shape, WinoGemmPolicy, ABLATE, 2>), grid, dim3(Shape::THREADS), 0, 0, g);
+        else if constexpr (V0 == 3)
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2>), grid, dim3(256), 0, 0, g);
+        else if constexpr (V0 == 4)
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<3>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 2)
             hipLaunchKernelGGL((gemm_mfma_kernel_p3<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
         else
@@ -78,6 +86,39 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     CK(hipEventElapsedTime(&ms, a, b));
     ms /= reps;
     const double tf = 2.0 * g_batches * cs.K * cs.C * (double)cs.P / ms / 1e9;
+    // correctness against the first variant run for this case: planes xi = 0 and xi = batches-1, valid rows / columns only
+    {
+        static std::vector<float> ref[2];
+        static Case ref_case{0, 0, 0};
+        std::vector<float> got[2];
+        const size_t plane = (size_t)cs.K * g.Pp;
+        const bool fresh = ref_case.C != cs.C || ref_case.K != cs.K || ref_case.P != cs.P;
+        for (int w = 0; w < 2; ++w)
+        {
+            got[w].resize(plane);
+            CK(hipMemcpy(got[w].data(), M + (size_t)(w ? g_batches - 1 : 0) * plane, plane * 4, hipMemcpyDeviceToHost));
+        }
+        if (fresh && ABLATE == 0 && V0 == 0)
+        {
+            ref[0] = got[0];
+            ref[1] = got[1];
+            ref_case = cs;
+            g_ref_pp = g.Pp;
+        }
+        else if (!fresh && ABLATE == 0 && g.Pp == g_ref_pp)
+        {
+            double worst = 0, scale = 0;
+            for (int w = 0; w < 2; ++w)
+                for (int m = 0; m < cs.K; ++m)
+                    for (int p = 0; p < cs.P; ++p)
+                    {
+                        const double a = got[w][(size_t)m * g.Pp + p], b = ref[w][(size_t)m * g.Pp + p];
+                        worst = std::max(worst, std::abs(a - b));
+                        scale = std::max(scale, std::abs(b));
+                    }
+            if (worst > 1e-5 * scale) printf("    !! %s differs from the product kernel: max |diff| %.3e (scale %.3e)\n", name, worst, scale);
+        }
+    }
     printf("  %-34s C%4d K%4d P%6d grid %6d  %8.4f ms  %7.2f TF (%.1f%% of 157.3)\n", name, cs.C, cs.K, cs.P, grid.x, ms, tf, tf / 157.3 * 100);
     return tf;
 }
@@ -85,7 +126,7 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
 int main(int argc, char** argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
-    const Case cases[] = {{256, 256, 3200}, {512, 512, 800}, {512, 512, 288}, {128, 128, 11552}, {64, 64, 46208}, {64, 128, 11552}};
+    const Case cases[] = {{128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}, {64, 128, 11552}};
     size_t maxU = 0, maxV = 0, maxM = 0;
     for (auto& c : cases)
     {
@@ -128,9 +169,8 @@ int main(int argc, char** argv)
         for (int round = 0; round < 3; ++round)
         {
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("128x64x16 2x2 (product)", c, U, V, M, reps);
-            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 2>("128x64x16 2x2 p3", c, U, V, M, reps);
-            run<GemmShape<64, 128, 16, 1, 4, 4>, 0>("64x128x16 1x4 (small-M)", c, U, V, M, reps);
-            run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 2>("64x128x16 1x4 p3", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>("128x64x16 glds 2 buffers", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 4>("128x64x16 glds 3 buffers", c, U, V, M, reps);
         }
     }
     return 0;

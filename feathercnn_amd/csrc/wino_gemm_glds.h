@@ -18,10 +18,11 @@ namespace fhip
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int NBUF>
-__global__ __launch_bounds__(256, 4) void wino_gemm_glds_kernel(const WinoGemmPolicy::Params prm)
+template <int NBUF, int BK = 16>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 3) void wino_gemm_glds_kernel(const WinoGemmPolicy::Params prm)
 {
-    constexpr int BM = 128, BN = 64, BK = 16, EPI_LD = 36;
+    constexpr int BM = 128, BN = 64, EPI_LD = 36;
+    constexpr int RPW = BK / 4; // k rows per wave and tile
     constexpr int BUF_FLOATS = BK * (BM + BN); // A [16][128] then B [16][64]
     constexpr int LDSF = NBUF * BUF_FLOATS > 4 * 32 * EPI_LD ? NBUF * BUF_FLOATS : 4 * 32 * EPI_LD;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
@@ -40,19 +41,24 @@ __global__ __launch_bounds__(256, 4) void wino_gemm_glds_kernel(const WinoGemmPo
     const int l31 = lane & 31, half = lane >> 5;
 
     // per-lane sources.  A: wave w, piece i covers rows 4w + 2i, 4w + 2i + 1 (32 lanes x 16 B per row)
-    const float* srcA = prm.U + (size_t)xi * prm.Cp * prm.Kp + (size_t)(wave * 4 + half) * prm.Kp + m0 + l31 * 4;
-    // B: wave w covers rows 4w .. 4w+3 (16 lanes x 16 B per row)
-    const int brow = wave * 4 + (lane >> 4);
+    const float* srcA = prm.U + (size_t)xi * prm.Cp * prm.Kp + (size_t)(wave * RPW + half) * prm.Kp + m0 + l31 * 4;
+    // B: wave w covers rows RPW*w .. RPW*w + RPW-1 (16 lanes x 16 B per row, 4 rows per piece)
+    const int brow = wave * RPW + (lane >> 4);
     const float* srcB = prm.V + (size_t)xi * prm.C * prm.Pp + n0 + (lane & 15) * 4;
     const size_t a_step = (size_t)BK * prm.Kp;
 
     auto issue = [&](int kt, int buf) {
         float* base = lds + buf * BUF_FLOATS;
         const float* a = srcA + (size_t)kt * a_step;
-        __builtin_amdgcn_global_load_lds(a, (lds_void*)(base + (wave * 4) * BM), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(a + 2 * (size_t)prm.Kp, (lds_void*)(base + (wave * 4 + 2) * BM), 16, 0, 0);
-        const int r = min(kt * BK + brow, prm.C - 1);
-        __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp, (lds_void*)(base + BK * BM + (wave * 4) * BN), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RPW / 2; ++i)
+            __builtin_amdgcn_global_load_lds(a + (size_t)(2 * i) * prm.Kp, (lds_void*)(base + (wave * RPW + 2 * i) * BM), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RPW / 4; ++i)
+        {
+            const int r = min(kt * BK + brow + 4 * i, prm.C - 1);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp, (lds_void*)(base + BK * BM + (wave * RPW + 4 * i) * BN), 16, 0, 0);
+        }
     };
 
     f32x16 acc[2];

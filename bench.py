@@ -248,7 +248,7 @@ def make_roofline(net_name, gemm_flops, gemm_ms, dw_bytes, dw_ms):
                             "sum of their HIP-event durations"}
     elif gemm_ms > 0:
         ach = gemm_flops / gemm_ms / 1e9
-        roofline = {"kernel": "gemm_mfma_kernel<WinoGemmPolicy> (Winograd tile GEMM)", "bound": "mfma", "achieved": round(ach, 2),
+        roofline = {"kernel": "Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
                     "note": "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
                             "sum of their tile-GEMM HIP-event durations"}

@@ -245,13 +245,15 @@ def make_roofline(net_name, gemm_flops, gemm_ms, dw_bytes, dw_ms):
         roofline = {"kernel": "depthwise3x3_direct_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                     "note": "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C summed over the 13 depthwise launches of a step / "
-                            "sum of their HIP-event durations"}
+                            "sum of their HIP-event durations on the launch stream, taken in an eager pass of the same step right after the "
+                            "timed region"}
     elif gemm_ms > 0:
         ach = gemm_flops / gemm_ms / 1e9
         roofline = {"kernel": "Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
                     "note": "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
-                            "sum of their tile-GEMM HIP-event durations"}
+                            "sum of their tile-GEMM HIP-event durations on the launch stream, taken in an eager pass of the same step right "
+                            "after the timed region (the timed steps replay a hipGraph, which cannot carry per-kernel events)"}
     if roofline is not None:
         roofline.update(pmc_traffic(net_name, roofline["bound"]))
     return roofline

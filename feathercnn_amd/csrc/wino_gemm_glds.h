@@ -18,8 +18,8 @@ namespace fhip
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int NBUF, int BK = 16>
-__global__ __launch_bounds__(256, BK == 16 ? 4 : 3) void wino_gemm_glds_kernel(const WinoGemmPolicy::Params prm)
+template <int NBUF, int BK = 16, int OCC = 6>
+__global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel(const WinoGemmPolicy::Params prm)
 {
     constexpr int BM = 128, BN = 64, EPI_LD = 36;
     constexpr int RPW = BK / 4; // k rows per wave and tile

@@ -67,7 +67,11 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
         else if constexpr (V0 == 3)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 4)
-            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 32>), grid, dim3(256), 0, 0, g);
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 5>), grid, dim3(256), 0, 0, g);
+        else if constexpr (V0 == 5)
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6>), grid, dim3(256), 0, 0, g);
+        else if constexpr (V0 == 6)
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 3>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 2)
             hipLaunchKernelGGL((gemm_mfma_kernel_p3<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
         else
@@ -170,7 +174,9 @@ int main(int argc, char** argv)
         {
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("128x64x16 2x2 (product)", c, U, V, M, reps);
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>("128x64x16 glds 2 buffers", c, U, V, M, reps);
-            run<GemmShape<128, 64, 32, 2, 2, 3>, 0, 4>("128x64x32 glds 2 buffers", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 4>("glds occupancy 5", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 5>("glds occupancy 6", c, U, V, M, reps);
+            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 6>("glds occupancy 3", c, U, V, M, reps);
         }
     }
     return 0;

@@ -130,7 +130,8 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
 int main(int argc, char** argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
-    const Case cases[] = {{128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}, {64, 128, 11552}};
+    // the Winograd tile-GEMM shapes of VGG-16 at batch 32 (C, K, P)
+    const Case cases[] = {{64, 64, 46208}, {64, 128, 11552}, {128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}};
     size_t maxU = 0, maxV = 0, maxM = 0;
     for (auto& c : cases)
     {
@@ -174,9 +175,11 @@ int main(int argc, char** argv)
         {
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("128x64x16 2x2 (product)", c, U, V, M, reps);
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>("128x64x16 glds 2 buffers", c, U, V, M, reps);
-            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 4>("glds occupancy 5", c, U, V, M, reps);
-            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 5>("glds occupancy 6", c, U, V, M, reps);
-            run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 6>("glds occupancy 3", c, U, V, M, reps);
+            run<GemmShape<64, 128, 16, 1, 4, 4>, 0>("64x128 1x4 (product small-M)", c, U, V, M, reps);
+            run<GemmShape<64, 64, 16, 2, 2, 8>, 0>("64x64 2x2 occ 8", c, U, V, M, reps);
+            run<GemmShape<64, 64, 16, 1, 2, 8>, 0>("64x64 1x2 (2 waves) occ 8", c, U, V, M, reps);
+            run<GemmShape<64, 128, 16, 1, 4, 6>, 0>("64x128 1x4 occ 6", c, U, V, M, reps);
+            run<GemmShape<64, 256, 16, 1, 4, 3>, 0>("64x256 1x4 occ 3", c, U, V, M, reps);
         }
     }
     return 0;

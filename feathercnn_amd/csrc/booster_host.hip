@@ -43,6 +43,40 @@ static fhip_conv_param to_c(const ConvParam* p)
 
 static int batch_of(const ConvParam* p) { return p->batch > 0 ? p->batch : 1; }
 
+// ---- ConvParam members (reference booster.h:113-148), on top of the C-ABI so there is one definition of every rule -------------
+BOOSTER_EXPORT void ConvParam::AssignOutputDim()
+{
+    fhip_conv_param c = to_c(this);
+    fhip_conv_assign_output_dim(&c);
+    group = c.group;
+    stride_h = c.stride_h;
+    stride_w = c.stride_w;
+    output_h = c.output_h;
+    output_w = c.output_w;
+    output_channels = c.output_channels;
+}
+
+BOOSTER_EXPORT void ConvParam::AssignPaddedDim()
+{
+    input_h += pad_top + pad_bottom;
+    input_w += pad_left + pad_right;
+    pad_left = pad_bottom = pad_right = pad_top = 0;
+}
+
+BOOSTER_EXPORT void ConvParam::LogParams(const char* layer_name)
+{
+    printf("ConvParam of layer %s: in %d x %d x %d, out %d x %d x %d, kernel %d x %d, stride %d x %d, pads l%d b%d r%d t%d, group %d, bias %d, "
+           "activation %d, batch %d\n",
+           layer_name, input_channels, input_h, input_w, output_channels, output_h, output_w, kernel_h, kernel_w, stride_h, stride_w, pad_left,
+           pad_bottom, pad_right, pad_top, group, bias_term ? 1 : 0, (int)activation, batch_of(this));
+}
+
+BOOSTER_EXPORT double ConvParam::GetFLOPS()
+{
+    const fhip_conv_param c = to_c(this);
+    return fhip_conv_flops(&c);
+}
+
 template <int ALGO>
 static int T_GetBufferSize(ConvParam* param, int* buffer_size, int* processed_kernel_size)
 {

@@ -24,75 +24,30 @@
 namespace booster
 {
 
-enum ConvAlgo
-{
-    NAIVE,
-    IM2COL,
-    SGECONV,
-    DEPTHWISE,
-    WINOGRADF63,
-    WINOGRADF63FUSED,
-    WINOGRADF23,
-};
+// Same enumerators and numeric values as the reference (booster.h:42-57): they travel through the C-ABI as plain ints.
+enum ConvAlgo { NAIVE, IM2COL, SGECONV, DEPTHWISE, WINOGRADF63, WINOGRADF63FUSED, WINOGRADF23 };
+enum ActivationType { None, ReLU };
 
-enum ActivationType
-{
-    None,
-    ReLU,
-};
-
+// Field for field and in the same order as the reference struct (booster.h:59-77), so host code that fills a ConvParam
+// compiles and lays out unchanged; `batch` is appended.  The member functions keep the reference's names and meaning but
+// live in libfeather_hip.so (booster_host.hip) on top of the C-ABI, so host and device can never disagree about a dimension.
 struct ConvParam
 {
-    int output_channels;
-    int input_channels;
-    int input_h;
-    int input_w;
-    int kernel_h;
-    int kernel_w;
-    int output_h;
-    int output_w;
-    int stride_h;
-    int stride_w;
-    int pad_left;
-    int pad_bottom;
-    int pad_right;
-    int pad_top;
+    int output_channels, input_channels;
+    int input_h, input_w;
+    int kernel_h, kernel_w;
+    int output_h, output_w;
+    int stride_h, stride_w;
+    int pad_left, pad_bottom, pad_right, pad_top;
     int group;
     bool bias_term;
     ActivationType activation;
     int batch; // GPU extension: images per Forward; 0 means 1
 
-    void AssignOutputDim()
-    {
-        if (group == 0) group = 1;
-        if (stride_h == 0) stride_h = 1;
-        if (stride_w == 0) stride_w = 1;
-        output_h = (input_h + pad_top + pad_bottom - kernel_h) / stride_h + 1;
-        output_w = (input_w + pad_left + pad_right - kernel_w) / stride_w + 1;
-        if (group == input_channels) output_channels = input_channels;
-    }
-    void AssignPaddedDim()
-    {
-        input_h = input_h + pad_top + pad_bottom;
-        input_w = input_w + pad_left + pad_right;
-        pad_left = pad_bottom = pad_right = pad_top = 0;
-    }
-    void LogParams(const char* layer_name)
-    {
-        printf("-----Layer %s ConvParam----\n", layer_name);
-        printf("Input CxHxW=(%d, %d, %d)\n", input_channels, input_h, input_w);
-        printf("Output CxHxW=(%d, %d, %d)\n", output_channels, output_h, output_w);
-        printf("Group = %d\n", group);
-        printf("Kernel HxW=(%d, %d)\n", kernel_h, kernel_w);
-        printf("Stride HxW=(%d, %d)\n", stride_h, stride_w);
-        printf("Paddings (%d %d %d %d)\n", pad_left, pad_bottom, pad_right, pad_top);
-        printf("Batch = %d\n", batch > 0 ? batch : 1);
-    }
-    double GetFLOPS()
-    {
-        return 2.0 * this->output_channels * this->input_channels * this->output_h * this->output_w * this->kernel_h *
-               this->kernel_w / this->group;
-    }
+    void AssignOutputDim();                   // fhip_conv_assign_output_dim: defaults, floor dims, depthwise oc = ic
+    void AssignPaddedDim();                   // fold the pads into input_h / input_w and clear them
+    void LogParams(const char* layer_name);   // one block of text on stdout
+    double GetFLOPS();                        // fhip_conv_flops, per image
 };
 
 typedef int (*GET_BUFFER_SIZE_FUNC)(ConvParam* param, int* buffer_size, int* processed_kernel_size);

@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: all cores, max 64)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
     ap.add_argument("--mode", default="net", choices=["net", "convstack"])
+    ap.add_argument("--no-overlap", action="store_true", help="net mode: keep every layer on one stream (no branch concurrency)")
     ap.add_argument("--reference-selection", action="store_true",
                     help="route convolutions with the reference's SelectAlgo rule instead of the MI355X cost model (fhip_conv_select_algo_tuned)")
     ap.add_argument("--fusion", type=int, default=2, help="net mode: 0 none, 1 the reference's TryFuse patterns, 2 also fold BN/Scale into conv weights")
@@ -285,7 +286,7 @@ def setup_net(a, env):
     from feathercnn_amd.shard import broadcast_model
     model, t_bcast, bcast_bytes = broadcast_model(build, dev, src=0)
     p, b, in_name, out_name = model
-    net = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection)
+    net = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection, concurrency=not a.no_overlap)
     net.LoadParam(p)
     net.LoadWeights(b)
     gen = torch.Generator(device=dev)
@@ -523,7 +524,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": extra.pop("workload"), "net": a.net, "mode": a.mode, "per_gpu_batch": batch, "global_batch": total_images,
                        "parallelism": f"batch-shard x{n_gpus}", "launch": extra.pop("launch"),
-                       "conv_routing": "reference SelectAlgo rule" if a.reference_selection else "fhip_conv_select_algo_tuned (Winograd also on 4..8-pixel 3x3 layers)"},
+                       "conv_routing": "reference SelectAlgo rule" if a.reference_selection else "fhip_conv_select_algo_tuned (Winograd also on 4..8-pixel 3x3 layers)",
+                       "streams": "one" if (a.no_overlap or a.mode != "net") else "main + one side stream for arena-free branch convolutions"},
         }
         roofline = extra.pop("roofline", None)
         res.update(extra)

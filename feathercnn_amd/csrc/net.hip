@@ -353,10 +353,20 @@ struct Net
     DeviceVec arena;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t owned_stream = nullptr; // graph capture is not allowed on the NULL stream
+    // Branch concurrency (fhip_net_set_concurrency): a convolution that needs no scratch arena and whose output is consumed
+    // only further down the layer list (ResNet's projection shortcut, SqueezeNet's expand1x1) runs on a second stream while the
+    // main stream continues with the layers in between; fork / join are events, so the pattern is hipGraph-capturable.
+    bool concurrency = false;
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> events;        // [2 * pair]: fork, join
+    std::vector<int> side;                 // per layer: its event pair, or -1 (runs on the main stream)
+    std::vector<std::vector<int>> waits;   // per layer: pairs whose join event the main stream waits for first
 
     ~Net()
     {
         drop_graph();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
         if (owned_stream) (void)hipStreamDestroy(owned_stream);
     }
     void drop_graph()
@@ -528,6 +538,7 @@ struct ConvLayer : Layer
     {
         if (fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
         residual = other;
+        bottoms.push_back(other); // so that dependency scans (fusion, branch concurrency) see the second input
         return true;
     }
     size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes; }
@@ -1103,6 +1114,46 @@ static void fuse_layers(Net& net)
     }
 }
 
+// Which layers may leave the main stream (see Net::concurrency).  Needs the algorithms chosen by Reshape: only layers without
+// scratch (the arena is shared) qualify.
+static int plan_concurrency(Net& net)
+{
+    const size_t L = net.layers.size();
+    net.side.assign(L, -1);
+    net.waits.assign(L, std::vector<int>());
+    if (!net.concurrency) return 0;
+    int pairs = 0;
+    for (size_t i = 0; i < L; ++i)
+    {
+        Layer* l = net.layers[i].get();
+        if ((l->type != "Convolution" && l->type != "ConvolutionDepthWise") || l->arena_bytes() != 0 || l->tops.size() != 1) continue;
+        size_t consumer = 0;
+        int uses = 0;
+        for (size_t j = i + 1; j < L; ++j)
+            for (Blob* b : net.layers[j]->bottoms)
+                if (b == l->tops[0] || b->alias == l->tops[0])
+                {
+                    ++uses;
+                    consumer = j;
+                }
+        if (uses != 1 || consumer <= i + 1) continue;
+        bool work_between = false; // something worth overlapping with
+        for (size_t j = i + 1; j < consumer; ++j) work_between = work_between || net.layers[j]->algo() >= 0;
+        if (!work_between) continue;
+        net.side[i] = pairs;
+        net.waits[consumer].push_back(pairs);
+        ++pairs;
+    }
+    if (pairs && !net.side_stream) FHIP_CHECK_HIP(hipStreamCreateWithFlags(&net.side_stream, hipStreamNonBlocking));
+    while (net.events.size() < (size_t)2 * pairs)
+    {
+        hipEvent_t e;
+        FHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        net.events.push_back(e);
+    }
+    return 0;
+}
+
 static int reshape_all(Net& net)
 {
     net.drop_graph();
@@ -1120,7 +1171,7 @@ static int reshape_all(Net& net)
         if (rc) return rc;
     }
     net.shapes_dirty = false;
-    return 0;
+    return plan_concurrency(net);
 }
 
 static int prepare(Net& net)
@@ -1159,8 +1210,21 @@ static int prepare(Net& net)
 
 static int run_layers(Net& net)
 {
-    for (auto& l : net.layers)
+    for (size_t i = 0; i < net.layers.size(); ++i)
     {
+        Layer* l = net.layers[i].get();
+        if (i < net.side.size() && net.side[i] >= 0)
+        {
+            hipEvent_t fork = net.events[2 * net.side[i]], join = net.events[2 * net.side[i] + 1];
+            FHIP_CHECK_HIP(hipEventRecord(fork, net.stream)); // everything this layer reads is produced earlier on the main stream
+            FHIP_CHECK_HIP(hipStreamWaitEvent(net.side_stream, fork, 0));
+            const int rc = l->Forward(net.side_stream);
+            if (rc) return rc;
+            FHIP_CHECK_HIP(hipEventRecord(join, net.side_stream));
+            continue;
+        }
+        if (i < net.waits.size())
+            for (int pair : net.waits[i]) FHIP_CHECK_HIP(hipStreamWaitEvent(net.stream, net.events[2 * pair + 1], 0));
         const int rc = l->Forward(net.stream);
         if (rc) return rc;
     }
@@ -1245,6 +1309,14 @@ int fhip_net_set_tuned_selection(fhip_net* n, int on)
     NET_GUARD(n);
     n->impl.tuned_selection = on != 0;
     n->impl.shapes_dirty = true;
+    return FHIP_OK;
+}
+
+int fhip_net_set_concurrency(fhip_net* n, int on)
+{
+    NET_GUARD(n);
+    n->impl.concurrency = on != 0;
+    n->impl.shapes_dirty = true; // re-plan (and drop a captured graph) at the next Forward
     return FHIP_OK;
 }
 

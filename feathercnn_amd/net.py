@@ -12,7 +12,7 @@ from .booster import ALGO_NAMES, FeatherHipError, _check, _stream
 
 
 class Net:
-    def __init__(self, fusion: int = 1, graph: bool = False, stream=None, tuned: bool = False):
+    def __init__(self, fusion: int = 1, graph: bool = False, stream=None, tuned: bool = False, concurrency: bool = False):
         self._lib = _lib.load_library()
         h = ctypes.c_void_p()
         _check(self._lib.fhip_net_create(ctypes.byref(h)), "fhip_net_create")
@@ -20,6 +20,7 @@ class Net:
         _check(self._lib.fhip_net_set_fusion(h, int(fusion)), "fhip_net_set_fusion")
         _check(self._lib.fhip_net_set_graph(h, int(bool(graph))), "fhip_net_set_graph")
         _check(self._lib.fhip_net_set_tuned_selection(h, int(bool(tuned))), "fhip_net_set_tuned_selection")
+        _check(self._lib.fhip_net_set_concurrency(h, int(bool(concurrency))), "fhip_net_set_concurrency")
         if stream is not None:
             _check(self._lib.fhip_net_set_stream(h, ctypes.c_void_p(stream)), "fhip_net_set_stream")
 

@@ -67,6 +67,7 @@ class Net
     int SetFusion(int level) { return fhip_net_set_fusion(net_, level); }
     int SetGraph(bool on) { return fhip_net_set_graph(net_, on ? 1 : 0); }
     int SetTunedSelection(bool on) { return fhip_net_set_tuned_selection(net_, on ? 1 : 0); }
+    int SetConcurrency(bool on) { return fhip_net_set_concurrency(net_, on ? 1 : 0); }
     int LayerCount() { return fhip_net_layer_count(net_); }
     static const char* LastError() { return fhip_last_error(); }
     fhip_net* handle() { return net_; }

@@ -84,6 +84,10 @@ FHIP_API int fhip_net_set_fusion(fhip_net* net, int on);
 /* 1: convolutions choose their route with fhip_conv_select_algo_tuned (MI355X cost model) instead of the reference's
  * SelectAlgo rule; 0 (default): the reference rule. */
 FHIP_API int fhip_net_set_tuned_selection(fhip_net* net, int on);
+/* 1: independent branches run concurrently: a convolution that needs no scratch arena and whose output is only consumed
+ * further down the layer list (ResNet's projection shortcut, SqueezeNet's expand1x1) is enqueued on a second stream owned by
+ * the net while the main stream continues; fork and join are events (hipGraph-capturable).  0 (default): one stream. */
+FHIP_API int fhip_net_set_concurrency(fhip_net* net, int on);
 /* 1: after the first Forward for a shape, record the layer sequence into a hipGraph and replay it.  Capture is not
  * allowed on the NULL stream: if no stream was set, the net creates and uses its own non-blocking stream (order device
  * inputs produced on other streams yourself). */

@@ -108,12 +108,13 @@ def test_random_topology(seed, cuda):
     want = blobs[out]
     scale = float(np.abs(want).max())
     assert np.isfinite(want).all() or np.isnan(want).any()  # empty average windows are NaN on both sides
-    for fusion, tuned in [(0, False), (1, False), (2, False), (2, True)]:
-        net = Net(fusion=fusion, tuned=tuned)
+    for fusion, tuned, conc in [(0, False, False), (1, False, True), (2, False, False), (2, True, True)]:
+        net = Net(fusion=fusion, tuned=tuned, concurrency=conc, graph=conc and seed % 2 == 0)
         net.LoadParam(p)
         net.LoadWeights(b)
         net.FeedInput("data", img)
-        net.Forward()
+        for _ in range(3 if conc else 1):
+            net.Forward()
         got = net.Extract(out)
         assert got.shape == want.shape, (seed, fusion)
         ok = ~np.isnan(want)

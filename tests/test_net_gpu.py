@@ -400,3 +400,27 @@ def test_tuned_selection_routes_small_3x3_layers_to_winograd_and_keeps_parity(cu
     for tuned in (False, True):
         assert nerr(outs[tuned][0], want_logits) <= TOL, tuned
         assert nerr(outs[tuned][1], want) <= TOL, tuned
+
+
+@pytest.mark.parametrize("name,batch", [("resnet50", 3), ("squeezenet_v1.1", 4)])
+@pytest.mark.parametrize("graph", [False, True])
+def test_branch_concurrency_keeps_results_bit_identical(cuda, name, batch, graph):
+    """fhip_net_set_concurrency moves arena-free convolutions with a distant consumer (projection shortcuts, expand1x1) to a second
+    stream.  Same kernels, same inputs: the outputs must equal the single-stream run bit for bit, run after run."""
+    from feathercnn_amd.net import Net
+    p, b, i, o = model_zoo.MODELS[name]()
+    x = np.random.default_rng(31).uniform(-1, 1, (batch, 3, 224, 224)).astype(np.float32)
+    outs = []
+    for conc in (False, True):
+        net = Net(fusion=2, tuned=True, concurrency=conc, graph=graph)
+        net.LoadParam(p)
+        net.LoadWeights(b)
+        net.FeedInput(i, x)
+        runs = []
+        for _ in range(4 if conc else 1):
+            net.Forward()
+            runs.append(net.Extract(o).copy())
+        assert all(np.array_equal(runs[0], r) for r in runs)
+        outs.append(runs[0])
+        net.close()
+    assert np.array_equal(outs[0], outs[1])

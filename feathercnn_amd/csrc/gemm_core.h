@@ -71,6 +71,7 @@ struct GemmShape
 //        from clamped addresses, `ok` bit e = element e is real data, zero-fill happens at LDS-write time)
 //   struct Store { Store(const Params&, int batch, int n4); void put4(const Params&, int m, float4 v) const; };
 //       (4 consecutive output columns n4..n4+3 of row m)
+//   static int k_count(const Params&, int batch);   k-tiles this batch entry reduces over (the loaders know where they start)
 //
 // ABLATE (measurement builds only, tools/gemm_bench.hip; the product always uses 0):
 //   bit 0: no global fetch after the prologue (MFMA + LDS only; results are garbage), bit 1: no accumulator store.
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     const int nt = vid % prm.n_tiles;
     const int batch = vid / prm.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int k_tiles = prm.k_tiles;
+    const int k_tiles = Policy::k_count(prm, batch); // tiles of THIS batch entry (a split-K piece may be uneven)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

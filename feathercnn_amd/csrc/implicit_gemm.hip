@@ -33,7 +33,10 @@ struct ConvGemmParams
     int OHW, HW, KHW;
     int has_bias, relu;
     // split-K (under-filled grids): the GEMM "batch" index is the K split; split s reduces k-tiles
-    // [s*k_tiles, (s+1)*k_tiles) and writes raw partial sums to partial[s][K][Ntot]; a reduce kernel finishes
+    // [s*k_tiles/S, (s+1)*k_tiles/S) of the k_tiles in total (pieces may differ by one tile) and writes raw partial sums to
+    // partial[s][K][Ntot]; a reduce kernel finishes.  (An in-kernel fix-up -- the block that draws a tile's last ticket sums the
+    // pieces -- was built and measured 3x SLOWER: the pieces of a tile run on different XCDs, whose L2s are only made coherent by
+    // agent-scope fences, and every such fence writes back the whole L2.)
     int split_k;
     float* partial;
     // optional residual (same layout as out), added before the activation: out = act(conv + bias + residual);
@@ -50,13 +53,16 @@ struct ConvGemmPolicy
 {
     using Params = ConvGemmParams;
 
+    static __device__ int k_first(const Params& p, int split) { return (int)((long long)split * p.k_tiles / p.split_k); }
+    static __device__ int k_count(const Params& p, int split) { return k_first(p, split + 1) - k_first(p, split); }
+
     struct ALoad
     {
         const float* base;
         // panel-major weights: the rows a block streams are ONE contiguous run of memory (k-tile after k-tile), which is what
         // the InnerProduct shapes need from HBM (VGG fc6: 32 panels of 12.8 MB, each read once by the blocks of one panel)
         __device__ ALoad(const Params& p, int split, int m4)
-            : base(p.Wt + ((size_t)(m4 / p.bm) * p.Kdp + (size_t)split * p.k_tiles * kConvKTile) * p.bm + (m4 % p.bm))
+            : base(p.Wt + ((size_t)(m4 / p.bm) * p.Kdp + (size_t)k_first(p, split) * kConvKTile) * p.bm + (m4 % p.bm))
         {
         }
         __device__ float4 load(const Params& p, int krow) const
@@ -74,7 +80,7 @@ struct ConvGemmPolicy
         __device__ BLoad(const Params& p, int split, int n4)
         {
             valid = 0;
-            koff = split * p.k_tiles * kConvKTile;
+            koff = k_first(p, split) * kConvKTile;
             if (MODE == 2)
             {
                 // 4 consecutive columns stay inside one image (OHW % 4 == 0, n4 % 4 == 0)
@@ -265,16 +271,19 @@ static int igemm_split(const fhip_conv_param& p, int batch)
         const char* e = getenv("FHIP_IGEMM_SPLIT");
         return e ? atoi(e) : 0;
     }();
-    if (forced > 0) return (kt % forced == 0) ? forced : 1;
     if (tiles >= 512 || kt < 16) return 1;
-    // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 32 tiles x 1568) stream the weight
-    // matrix once and are HBM bound: they want many more blocks in flight than the conv layers do
-    const bool deep = kt >= 512;
-    const int want = (int)std::min<long long>(deep ? 32 : 8, ((deep ? 1024 : 768) + tiles - 1) / tiles); // fc6: 64 tiles x 16 (measured best of 8..98)
-    int best = 1;
-    for (int s = 2; s <= want; ++s)
-        if (kt % s == 0 && kt / s >= 8) best = s;
-    return best;
+    if (forced > 0) return std::min(forced, kt);
+    int want;
+    if (kt >= 512)
+        // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 64 narrow tiles x 1568) stream the weight
+        // matrix once and are HBM bound: they want many blocks in flight (fc6: 16 pieces measured best of 8..98)
+        want = (int)std::min<long long>(32, (1024 + tiles - 1) / tiles);
+    else
+        // convolutions: as many pieces as keep ALL blocks resident at once (256 CUs x 5 blocks): equal blocks that start
+        // together finish together, whereas a grid just above the resident count pays a second, nearly empty round
+        want = (int)std::min<long long>(8, (long long)device_compute_units() * 5 / tiles);
+    want = std::min(want, kt / 8); // at least 8 k-tiles per piece
+    return std::max(want, 1);
 }
 
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
@@ -657,7 +666,7 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.split_k = igemm_split(p, batch);
     if (g.split_k > 1 && !buffer) return fail(FHIP_E_BADARG, "this geometry runs split-K and needs the scratch buffer GetBufferSize asked for");
     g.partial = buffer;
-    g.k_tiles = kdp / kConvKTile / g.split_k;
+    g.k_tiles = kdp / kConvKTile; // in total; a split reduces its share (ConvGemmPolicy::k_first / k_count)
     g.m_tiles = 0;
 
     const bool one = g.KH == 1 && g.KW == 1 && p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;

@@ -18,6 +18,7 @@ struct WinoGemmPolicy
         float* M;
         int C, K, Cp, Kp, Pp;
     };
+    static __device__ int k_count(const Params& p, int) { return p.k_tiles; }
     struct ALoad
     {
         const float* base;

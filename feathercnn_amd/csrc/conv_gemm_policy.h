@@ -1,0 +1,231 @@
+// conv_gemm_policy.h -- operand loaders / accumulator store of the implicit-GEMM convolution (IM2COL route) for the
+// shared fp32-MFMA main loop in gemm_core.h: the B-operand loader gathers booster::im2col's column matrix
+// (reference src/booster/avx/generic_kernels.cpp:50-85) straight from the NCHW input, the store applies the bias / ReLU /
+// residual epilogue of packed_sgemm_activation<bias,relu> (avx/sgemm.cpp:377-433).
+#pragma once
+
+#include "gemm_core.h"
+
+namespace fhip
+{
+
+constexpr int kConvKTile = 16;
+
+struct ConvGemmParams
+{
+    int batches, m_tiles, n_tiles, k_tiles;
+    const float* Wt;
+    const float* in;
+    float* out;
+    const float* bias;
+    int C, K, H, W, OH, OW, SH, SW, PL, PT, KH, KW;
+    int Kd;   // C*KH*KW
+    int Kp;   // padded output channels
+    int Kdp;  // padded reduction length (rows of a weight panel)
+    int bm;   // rows per weight panel = the kernel's BM: Wt is [Kp / bm panels][Kdp][bm]
+    int Ntot; // N*OH*OW
+    int OHW, HW, KHW;
+    int has_bias, relu;
+    // split-K (under-filled grids): the GEMM "batch" index is the K split; split s reduces k-tiles
+    // [s*k_tiles/S, (s+1)*k_tiles/S) of the k_tiles in total (pieces may differ by one tile) and writes raw partial sums to
+    // partial[s][K][Ntot]; a reduce kernel finishes.  (An in-kernel fix-up -- the block that draws a tile's last ticket sums the
+    // pieces -- was built and measured 3x SLOWER: the pieces of a tile run on different XCDs, whose L2s are only made coherent by
+    // agent-scope fences, and every such fence writes back the whole L2.)
+    int split_k;
+    float* partial;
+    // optional residual (same layout as out), added before the activation: out = act(conv + bias + residual);
+    // carried as a byte offset from `out` so the store path needs no second pointer table
+    int has_residual;
+    ptrdiff_t residual_delta;
+};
+
+// MODE 0: generic gather (any kernel / stride / pad)
+// MODE 1: 1x1, pad 0, any stride (no tap decode, no bounds checks)
+// MODE 2: 1x1, stride 1, pad 0, OH*OW % 4 == 0 : the column matrix IS the input -> 16-byte loads
+template <int MODE>
+struct ConvGemmPolicy
+{
+    using Params = ConvGemmParams;
+
+    static __device__ int k_first(const Params& p, int split) { return (int)((long long)split * p.k_tiles / p.split_k); }
+    static __device__ int k_count(const Params& p, int split) { return k_first(p, split + 1) - k_first(p, split); }
+
+    struct ALoad
+    {
+        const float* base;
+        // panel-major weights: the rows a block streams are ONE contiguous run of memory (k-tile after k-tile), which is what
+        // the InnerProduct shapes need from HBM (VGG fc6: 32 panels of 12.8 MB, each read once by the blocks of one panel)
+        __device__ ALoad(const Params& p, int split, int m4)
+            : base(p.Wt + ((size_t)(m4 / p.bm) * p.Kdp + (size_t)k_first(p, split) * kConvKTile) * p.bm + (m4 % p.bm))
+        {
+        }
+        __device__ float4 load(const Params& p, int krow) const
+        {
+            return *reinterpret_cast<const float4*>(base + (size_t)krow * p.bm); // Wt zero padded in both dims
+        }
+    };
+
+    struct BLoad
+    {
+        const float* ptr[MODE == 2 ? 1 : 4]; // &in[n][0][iy0][ix0] of each of the 4 columns (may point before the plane)
+        int iy0[MODE == 0 ? 4 : 1], ix0[MODE == 0 ? 4 : 1];
+        unsigned valid; // bit e: column n4+e < Ntot
+        int koff;       // first reduction row of this K split
+        __device__ BLoad(const Params& p, int split, int n4)
+        {
+            valid = 0;
+            koff = k_first(p, split) * kConvKTile;
+            if (MODE == 2)
+            {
+                // 4 consecutive columns stay inside one image (OHW % 4 == 0, n4 % 4 == 0)
+                const int img = n4 / p.OHW, rem = n4 - img * p.OHW;
+                valid = n4 < p.Ntot ? 0xfu : 0u;
+                ptr[0] = p.in + ((size_t)img * p.C) * p.HW + rem;
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const int col = n4 + e;
+                    const bool ok = col < p.Ntot;
+                    const int cc = ok ? col : 0;
+                    const int img = cc / p.OHW, rem = cc - img * p.OHW;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    const int y0 = oy * p.SH - p.PT, x0 = ox * p.SW - p.PL;
+                    if (MODE == 0)
+                    {
+                        iy0[e] = y0;
+                        ix0[e] = x0;
+                    }
+                    ptr[e] = p.in + ((size_t)img * p.C) * p.HW + (ptrdiff_t)y0 * p.W + x0;
+                    valid |= ok ? (1u << e) : 0u;
+                }
+            }
+        }
+        // Unconditional loads from clamped addresses; `ok` says which of the 4 values are real (see gemm_core.h).
+        __device__ float4 load(const Params& p, int krow_in_split, unsigned& ok) const
+        {
+            const int krow = krow_in_split + koff;
+            const bool kin = krow < p.Kd;
+            const int kr = min(krow, p.Kd - 1);
+            if (MODE == 2)
+            {
+                ok = kin ? valid : 0u;
+                return *reinterpret_cast<const float4*>((valid ? ptr[0] : p.in) + (size_t)kr * p.HW);
+            }
+            float v[4];
+            if (MODE == 1)
+            {
+                ok = kin ? valid : 0u;
+                const size_t koff = (size_t)kr * p.HW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ptr[e][koff]; // ptr[e] of an invalid column points at column 0
+            }
+            else
+            {
+                const int c = kr / p.KHW, r = kr - c * p.KHW;
+                const int u = r / p.KW, w = r - u * p.KW;
+                const ptrdiff_t koff = (ptrdiff_t)c * p.HW + (ptrdiff_t)u * p.W + w;
+                ok = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const bool in = kin && (valid & (1u << e)) && ((unsigned)(iy0[e] + u) < (unsigned)p.H) &&
+                                    ((unsigned)(ix0[e] + w) < (unsigned)p.W);
+                    ok |= in ? (1u << e) : 0u;
+                    v[e] = *(in ? ptr[e] + koff : p.in); // a padding tap reads in[0] and is zeroed at LDS-write time
+                }
+            }
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    struct Store
+    {
+        float* ptr[4]; // &out[img][0][rem] of each of the 4 columns
+        unsigned valid;
+        bool wide; // the 4 columns are one aligned 16-byte piece of one image
+        float* part; // split-K: &partial[split][0][n4]
+        __device__ Store(const Params& p, int split, int n4)
+        {
+            part = p.split_k > 1 ? p.partial + (size_t)split * p.K * p.Ntot + n4 : nullptr;
+            valid = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+            {
+                const int col = n4 + e;
+                const bool ok = col < p.Ntot;
+                const int cc = ok ? col : 0;
+                const int img = cc / p.OHW, rem = cc - img * p.OHW;
+                ptr[e] = p.out + ((size_t)img * p.K) * p.OHW + rem;
+                valid |= ok ? (1u << e) : 0u;
+            }
+            wide = (valid == 0xfu) && ((p.OHW & 3) == 0) && (ptr[3] == ptr[0] + 3);
+        }
+        __device__ void put4(const Params& p, int m, float4 v) const
+        {
+            if (m >= p.K) return;
+            if (part)
+            {
+                float* d = part + (size_t)m * p.Ntot;
+                if (valid == 0xfu && (p.Ntot & 3) == 0)
+                    *reinterpret_cast<float4*>(d) = v;
+                else
+                {
+                    if (valid & 1u) d[0] = v.x;
+                    if (valid & 2u) d[1] = v.y;
+                    if (valid & 4u) d[2] = v.z;
+                    if (valid & 8u) d[3] = v.w;
+                }
+                return;
+            }
+            if (p.has_bias)
+            {
+                const float b = p.bias[m];
+                v.x += b;
+                v.y += b;
+                v.z += b;
+                v.w += b;
+            }
+            const size_t moff = (size_t)m * p.OHW;
+            if (p.has_residual)
+            {
+                auto res = [&](const float* o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(o) + p.residual_delta); };
+                if (wide)
+                {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr[0] + moff) + p.residual_delta);
+                    v.x += r.x;
+                    v.y += r.y;
+                    v.z += r.z;
+                    v.w += r.w;
+                }
+                else
+                {
+                    if (valid & 1u) v.x += res(ptr[0] + moff);
+                    if (valid & 2u) v.y += res(ptr[1] + moff);
+                    if (valid & 4u) v.z += res(ptr[2] + moff);
+                    if (valid & 8u) v.w += res(ptr[3] + moff);
+                }
+            }
+            if (p.relu)
+            {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+            }
+            if (wide)
+                *reinterpret_cast<float4*>(ptr[0] + moff) = v;
+            else
+            {
+                if (valid & 1u) ptr[0][moff] = v.x;
+                if (valid & 2u) ptr[1][moff] = v.y;
+                if (valid & 4u) ptr[2][moff] = v.z;
+                if (valid & 8u) ptr[3][moff] = v.w;
+            }
+        }
+    };
+};
+
+} // namespace fhip

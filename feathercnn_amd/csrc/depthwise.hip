@@ -240,8 +240,11 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
             {
                 lft = __shfl_up(x[r][NV * VX], 1);
                 rgt = __shfl_down(x[r][1], 1);
-                if (lane == 0) lft = row[max(xb - 1, 0)];
-                if (lane == 63) rgt = row[min(xb + NV * VX, q.W - 1)];
+                // a neighbouring lane is a neighbour in the IMAGE only inside one row block: the first / last vector of a row
+                // (and the wave's edge lanes) load for real -- with pad_right != pad_left the last vector's right tap is a real
+                // pixel (OW * S < W), not padding
+                if (lane == 0 || xq == 0) lft = row[max(xb - 1, 0)];
+                if (lane == 63 || xq == xvecs - 1) rgt = row[min(xb + NV * VX, q.W - 1)];
             }
             else
             {

@@ -345,6 +345,10 @@ struct Net
 {
     std::vector<std::unique_ptr<Layer>> layers;
     std::map<std::string, std::unique_ptr<Blob>> blobs;
+    // Blobs whose NAME was taken over by a later top (in-place style files: `ReLU r 1 1 conv1 conv1`, or two layers with the
+    // same top).  The reference leaks the old Blob and replaces the map entry (net.cpp:135-139), so earlier layers keep
+    // using it; here it stays owned, the name resolves to the newest blob exactly like the reference's blob_map.
+    std::vector<std::unique_ptr<Blob>> shadowed;
     hipStream_t stream = nullptr;
     int fusion = 1;
     bool use_graph = false;
@@ -1019,7 +1023,9 @@ static int load_param_text(Net& net, const char* text, size_t len)
             std::unique_ptr<Blob> blob(new Blob);
             blob->name = tn;
             layer->tops.push_back(blob.get());
-            net.blobs[tn] = std::move(blob);
+            auto& slot = net.blobs[tn];
+            if (slot) net.shadowed.push_back(std::move(slot)); // earlier layers (and this layer's bottoms) still point at it
+            slot = std::move(blob);
         }
         pd.clear();
         while (t < tok.size() && ParamDict::looks_like_pair(tok[t]))
@@ -1466,6 +1472,7 @@ int fhip_net_memory(fhip_net* n, size_t* blob_bytes, size_t* weight_bytes, size_
     NET_GUARD(n);
     size_t bb = 0, wb = 0;
     for (auto& kv : n->impl.blobs) bb += kv.second->capacity * sizeof(float);
+    for (auto& b : n->impl.shadowed) bb += b->capacity * sizeof(float);
     for (auto& l : n->impl.layers) wb += l->weight_bytes();
     if (blob_bytes) *blob_bytes = bb;
     if (weight_bytes) *weight_bytes = wb;

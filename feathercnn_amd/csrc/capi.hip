@@ -21,8 +21,6 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
 int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
                               hipStream_t s, int pool = 0);
 bool winograd_can_pool(const fhip_conv_param& p);
-int winograd_fused_gemm_output(const fhip_conv_param& p, int batch, float* output, const float* u, const float* v, const float* bias,
-                               hipStream_t s);
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
@@ -32,9 +30,6 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
                       hipStream_t s);
 int depthwise_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 size_t depthwise_packed_floats(const fhip_conv_param& p, size_t* w12_offset);
-
-// Winograd sub-batch pipeline depth; FHIP_WINO_OVERLAP overrides
-constexpr int kWinoDefaultSub = 1; // measured: 2 sub-batches on two streams = 4.37 ms vs 3.87 ms per VGG step (smaller grids, no real overlap)
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -100,77 +95,6 @@ StageTimer::~StageTimer()
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_tm_mu);
     if (slot < (int)g_tm_pending.size()) (void)hipEventRecord(g_tm_pending[slot].b, stream);
-}
-
-// ---- Winograd sub-batch pipeline (see fhip_conv_forward) --------------------------------------------------------
-constexpr int kWinoMaxSub = 4;
-struct WinoSplit
-{
-    int n;
-    int first[kWinoMaxSub], count[kWinoMaxSub];
-    size_t v_off[kWinoMaxSub], m_off[kWinoMaxSub];
-    size_t total_bytes;
-};
-
-// How many sub-batches (pure function of geometry + batch + the FHIP_WINO_OVERLAP switch: GetBufferSize and Forward
-// must agree).  FHIP_WINO_OVERLAP = 0/1: no split; n >= 2: n sub-batches.
-static int wino_split(const fhip_conv_param& p, int batch, WinoSplit* sp)
-{
-    static const int env = [] {
-        const char* e = getenv("FHIP_WINO_OVERLAP");
-        return e ? atoi(e) : kWinoDefaultSub;
-    }();
-    int n = std::max(1, std::min(std::min(env, kWinoMaxSub), batch));
-    sp->n = n;
-    sp->total_bytes = 0;
-    int done = 0;
-    for (int i = 0; i < n; ++i)
-    {
-        const int cnt = batch / n + (i < batch % n ? 1 : 0);
-        fhip_winograd_plan pl;
-        int rc = winograd_plan(p, cnt, &pl);
-        if (rc) return rc;
-        sp->first[i] = done;
-        sp->count[i] = cnt;
-        sp->v_off[i] = sp->total_bytes + pl.v_offset_bytes;
-        sp->m_off[i] = sp->total_bytes + pl.m_offset_bytes;
-        sp->total_bytes += pl.v_bytes + pl.m_bytes;
-        done += cnt;
-    }
-    return FHIP_OK;
-}
-
-// second stream + events of the pipeline, one set per device, created on first use (fhip_conv_init touches it so that a
-// Forward under hipGraph capture never creates anything).  NULL while stage timing is on: timed runs stay on ONE stream so
-// that every kernel's event pair brackets that kernel alone.
-struct WinoAux
-{
-    hipStream_t comp;
-    hipEvent_t e2[kWinoMaxSub], e3[kWinoMaxSub];
-};
-static WinoAux* wino_aux()
-{
-    static std::mutex mu;
-    static WinoAux* tab[64] = {nullptr};
-    if (g_tm_on) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!tab[dev])
-    {
-        WinoAux* a = new WinoAux;
-        bool ok = hipStreamCreateWithFlags(&a->comp, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < kWinoMaxSub; ++i)
-            ok = hipEventCreateWithFlags(&a->e2[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&a->e3[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok)
-        {
-            delete a;
-            return nullptr;
-        }
-        tab[dev] = a;
-    }
-    return tab[dev];
 }
 
 static bool valid_param(const fhip_conv_param* p)
@@ -262,9 +186,7 @@ int fhip_conv_get_buffer_size(const fhip_conv_param* p, int algo, int batch, siz
             fhip_winograd_plan pl;
             int rc = winograd_plan(*p, batch, &pl);
             if (rc) return rc;
-            WinoSplit sp;
-            if ((rc = wino_split(*p, batch, &sp))) return rc;
-            *buffer_bytes = sp.total_bytes; // one V / M slice per pipelined sub-batch
+            *buffer_bytes = pl.v_bytes + pl.m_bytes; // V | M
             *packed_bytes = pl.u_bytes;
             return FHIP_OK;
         }
@@ -281,9 +203,7 @@ int fhip_conv_init(const fhip_conv_param* p, int algo, float* packed, const floa
         case FHIP_NAIVE:
         case FHIP_IM2COL: return igemm_init(*p, packed, kernel, s);
         case FHIP_DEPTHWISE: return depthwise_init(*p, packed, kernel, s);
-        case FHIP_WINOGRADF63:
-            (void)wino_aux(); // create the pipeline's stream / events now, never inside Forward
-            return winograd_transform_kernel(*p, packed, kernel, s);
+        case FHIP_WINOGRADF63: return winograd_transform_kernel(*p, packed, kernel, s);
         default: return fail(FHIP_E_UNSUPPORTED, "This algo is not supported on gfx950");
     }
 }
@@ -304,65 +224,15 @@ static int conv_forward_impl(const fhip_conv_param* p, int algo, int batch, floa
         case FHIP_WINOGRADF63:
         {
             if (!buffer) return fail(FHIP_E_BADARG, "Winograd needs the scratch buffer");
-            // measurement switch: FHIP_WINO_FUSED=1 forces the fused GEMM + output-transform kernel (measured slower)
-            static const int fused_env = [] {
-                const char* e = getenv("FHIP_WINO_FUSED");
-                return e ? atoi(e) : 0;
-            }();
-            WinoSplit sp;
-            int rc = wino_split(*p, batch, &sp);
+            // K2 -> K3 -> K4 back to back on the caller's stream; V and M live in the caller's scratch arena (winograd_plan)
+            fhip_winograd_plan pl;
+            int rc = winograd_plan(*p, batch, &pl);
             if (rc) return rc;
-            const size_t in_img = (size_t)p->input_channels * p->input_h * p->input_w;
-            const size_t out_img = (size_t)p->output_channels * p->output_h * p->output_w / (pool ? 4 : 1);
-            WinoAux* aux = (sp.n > 1 && !fused_env) ? wino_aux() : nullptr;
-            if (!aux)
-            {
-                // one stream, back to back (also the clean-timing mode)
-                for (int i = 0; i < sp.n; ++i)
-                {
-                    float* v = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.v_off[i]);
-                    float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.m_off[i]);
-                    const float* in_b = input + (size_t)sp.first[i] * in_img;
-                    float* out_b = output + (size_t)sp.first[i] * out_img;
-                    if ((rc = winograd_input_transform(*p, sp.count[i], v, in_b, s))) return rc;
-                    if (fused_env && !pool)
-                    {
-                        if ((rc = winograd_fused_gemm_output(*p, sp.count[i], out_b, packed, v, bias, s))) return rc;
-                        continue;
-                    }
-                    if ((rc = winograd_tile_gemm(*p, sp.count[i], m, packed, v, s))) return rc;
-                    if ((rc = winograd_output_transform(*p, sp.count[i], out_b, m, bias, s, pool))) return rc;
-                }
-                return FHIP_OK;
-            }
-            // Software pipeline over sub-batches: the HBM-bound transforms stay on the caller's stream, the MFMA-bound
-            // tile GEMMs go to a second stream, chained by events:  K2_i -> K3_i -> K4_i.  The caller's stream is issued
-            // K2_0, K2_1, K4_0, K2_2, K4_1, ... so the transforms of one sub-batch run under the GEMM of its neighbour.
-            // Every sub-batch has its own V / M slice of the scratch arena; the last kernels (K4) are on the caller's
-            // stream again, so later work on it is ordered as usual (and the fork/join is hipGraph-capturable).
-            for (int i = 0; i <= sp.n; ++i)
-            {
-                if (i < sp.n)
-                {
-                    float* v = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.v_off[i]);
-                    float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.m_off[i]);
-                    const float* in_b = input + (size_t)sp.first[i] * in_img;
-                    if ((rc = winograd_input_transform(*p, sp.count[i], v, in_b, s))) return rc;
-                    FHIP_CHECK_HIP(hipEventRecord(aux->e2[i], s));
-                    FHIP_CHECK_HIP(hipStreamWaitEvent(aux->comp, aux->e2[i], 0));
-                    if ((rc = winograd_tile_gemm(*p, sp.count[i], m, packed, v, aux->comp))) return rc;
-                    FHIP_CHECK_HIP(hipEventRecord(aux->e3[i], aux->comp));
-                }
-                if (i >= 1)
-                {
-                    const int j = i - 1;
-                    float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + sp.m_off[j]);
-                    float* out_b = output + (size_t)sp.first[j] * out_img;
-                    FHIP_CHECK_HIP(hipStreamWaitEvent(s, aux->e3[j], 0));
-                    if ((rc = winograd_output_transform(*p, sp.count[j], out_b, m, bias, s, pool))) return rc;
-                }
-            }
-            return FHIP_OK;
+            float* v = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.v_offset_bytes);
+            float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(buffer) + pl.m_offset_bytes);
+            if ((rc = winograd_input_transform(*p, batch, v, input, s))) return rc;
+            if ((rc = winograd_tile_gemm(*p, batch, m, packed, v, s))) return rc;
+            return winograd_output_transform(*p, batch, output, m, bias, s, pool);
         }
         default: return fail(FHIP_E_UNSUPPORTED, "This algo is not supported on gfx950");
     }

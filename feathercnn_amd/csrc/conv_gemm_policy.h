@@ -47,6 +47,8 @@ struct ConvGemmPolicy
 {
     using Params = ConvGemmParams;
 
+    // bias of output row m for the prologue preload (split-K pieces store raw partial sums: no bias)
+    static __device__ float bias_at(const Params& p, int m) { return (p.has_bias && p.split_k <= 1 && m < p.K) ? p.bias[m] : 0.f; }
     static __device__ int k_first(const Params& p, int split) { return (int)((long long)split * p.k_tiles / p.split_k); }
     static __device__ int k_count(const Params& p, int split) { return k_first(p, split + 1) - k_first(p, split); }
 
@@ -165,6 +167,10 @@ struct ConvGemmPolicy
         }
         __device__ void put4(const Params& p, int m, float4 v) const
         {
+            put4b(p, m, v, (p.has_bias && !part && m < p.K) ? p.bias[m] : 0.f);
+        }
+        __device__ void put4b(const Params& p, int m, float4 v, float b) const
+        {
             if (m >= p.K) return;
             if (part)
             {
@@ -180,14 +186,10 @@ struct ConvGemmPolicy
                 }
                 return;
             }
-            if (p.has_bias)
-            {
-                const float b = p.bias[m];
-                v.x += b;
-                v.y += b;
-                v.z += b;
-                v.w += b;
-            }
+            v.x += b;
+            v.y += b;
+            v.z += b;
+            v.w += b;
             const size_t moff = (size_t)m * p.OHW;
             if (p.has_residual)
             {

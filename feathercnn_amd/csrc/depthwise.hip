@@ -8,11 +8,10 @@
 // Three forms live here, chosen by shape (measurements in DESIGN.md 3.3):
 //   * depthwise3x3_direct_kernel  -- 3x3, stride 1/2, pad_left 1 (the MobileNet shapes).  NO LDS: every lane produces
 //     a VX-wide x R-high output patch straight from global memory with aligned vector loads, takes its two halo taps
-//     per row from the neighbouring lanes (cross-lane moves, not loads), and stores R vectors.  52-57 % of HBM peak.
-//   * depthwise3x3_lds_kernel / depthwise_lds_scalar_kernel -- the LDS-staged design BASELINE.json asks for: a block
-//     copies a chunk of whole planes global->LDS with coalesced 16-byte loads and computes from LDS.  Measured at
-//     24 % of peak on MobileNet-V1 (load / compute / store phases serialise inside a block at 2 blocks per CU);
-//     kept selectable (FHIP_DW_PATH=lds) and used for 3x3 shapes the direct form does not cover.
+//     per row from the neighbouring lanes (cross-lane moves, not loads), and stores R vectors.
+//   * depthwise_lds_scalar_kernel -- small planes of any other shape: a block copies a chunk of whole planes global->LDS with
+//     coalesced 16-byte loads and computes one output per lane from LDS.  (The whole-plane LDS staging BASELINE.json names for the
+//     3x3 case was built and measured at 24 % of HBM peak against 52 % for the direct form: tools/experiments)
 //   * depthwise_generic_kernel -- any kernel size / stride / plane size, one output per lane (incl. the reference's
 //     global-kernel special case).
 #include <stdlib.h>
@@ -35,117 +34,7 @@ struct DwParams
     int has_bias, relu;
 };
 
-constexpr int kDwLdsFloats = 14336; // 56 KiB of plane data per block (+ weights) -> 2 blocks per CU
-
-template <int S>
-__global__ __launch_bounds__(256) void depthwise3x3_lds_kernel(const DwParams q)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HW = q.H * q.W, OHW = q.OH * q.OW;
-    float* tile = smem;                                  // [planes_per_chunk][H][W]
-    float* wl = smem + (size_t)q.planes_per_chunk * HW;  // [planes_per_chunk][12]: 9 taps, bias, pad
-    const int tid = threadIdx.x;
-    const int chunks = (q.planes + q.planes_per_chunk - 1) / q.planes_per_chunk;
-    const int ow4 = q.OW >> 2, groups_per_plane = OHW >> 2;
-
-    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
-    {
-        const int plane0 = chunk * q.planes_per_chunk;
-        const int np = min(q.planes_per_chunk, q.planes - plane0);
-        // ---- stage: global -> LDS, 16 B per lane, fully coalesced -----------------------------------
-        {
-            // 8 independent 16-byte loads per lane in flight before the first LDS write (a plain copy loop is
-            // compiled load -> wait -> store and serialises on the HBM round trip: measured 3.4 -> TB/s)
-            const float4* src = reinterpret_cast<const float4*>(q.in + (size_t)plane0 * HW);
-            float4* dst = reinterpret_cast<float4*>(tile);
-            const int n4 = (np * HW) >> 2;
-            for (int i0 = tid; i0 < n4; i0 += 256 * 8)
-            {
-                float4 v[8];
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                {
-                    const int i = i0 + b * 256;
-                    v[b] = src[min(i, n4 - 1)];
-                }
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                {
-                    const int i = i0 + b * 256;
-                    if (i < n4) dst[i] = v[b];
-                }
-            }
-            for (int i = tid; i < np * 12; i += 256)
-            {
-                const int pl = i / 12, e = i - pl * 12;
-                const int c = (plane0 + pl) % q.C;
-                float v = 0.f;
-                if (e < 9) v = q.w[c * 9 + e];
-                else if (e == 9 && q.has_bias) v = q.bias[c];
-                wl[i] = v;
-            }
-        }
-        __syncthreads();
-        // ---- compute: 4 outputs of one row per lane -------------------------------------------------
-        const int ngroups = np * groups_per_plane;
-        float4* obase = reinterpret_cast<float4*>(q.out + (size_t)plane0 * OHW);
-        for (int gi = tid; gi < ngroups; gi += 256)
-        {
-            const int pl = gi / groups_per_plane, r = gi - pl * groups_per_plane;
-            const int oy = r / ow4, ox0 = (r - oy * ow4) << 2;
-            const float* wp = wl + pl * 12;
-            const float* ip = tile + (size_t)pl * HW;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            const int xb = ox0 * S; // first aligned quad of the taps; taps span [xb-1, xb+4*S]
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-            {
-                const int y = oy * S - q.PT + m;
-                if ((unsigned)y >= (unsigned)q.H) continue;
-                const float* row = ip + y * q.W;
-                // x[j] holds input column xb - 1 + j
-                float x[4 * S + 3];
-                {
-                    const int xl = xb - 4;
-                    const float4 L = *reinterpret_cast<const float4*>(row + max(xl, 0));
-                    x[0] = xl >= 0 ? L.w : 0.f;
-                }
-#pragma unroll
-                for (int qd = 0; qd < S; ++qd)
-                {
-                    const float4 Cq = *reinterpret_cast<const float4*>(row + xb + 4 * qd); // always inside the row
-                    x[1 + 4 * qd] = Cq.x;
-                    x[2 + 4 * qd] = Cq.y;
-                    x[3 + 4 * qd] = Cq.z;
-                    x[4 + 4 * qd] = Cq.w;
-                }
-                {
-                    const int xr = xb + 4 * S;
-                    const bool ok = xr < q.W;
-                    const float4 R = *reinterpret_cast<const float4*>(row + (ok ? xr : q.W - 4));
-                    x[4 * S + 1] = ok ? R.x : 0.f;
-                    if (S == 2) x[4 * S + 2] = ok ? R.y : 0.f; // never used by a tap; keeps the array dense
-                }
-                const float w0 = wp[m * 3 + 0], w1 = wp[m * 3 + 1], w2 = wp[m * 3 + 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                {
-                    acc[e] += x[e * S + 0] * w0;
-                    acc[e] += x[e * S + 1] * w1;
-                    acc[e] += x[e * S + 2] * w2;
-                }
-            }
-            const float b = wp[9];
-            float4 o;
-            o.x = apply_act(acc[0] + b, q.relu);
-            o.y = apply_act(acc[1] + b, q.relu);
-            o.z = apply_act(acc[2] + b, q.relu);
-            o.w = apply_act(acc[3] + b, q.relu);
-            obase[gi] = o;
-        }
-        __syncthreads();
-    }
-}
+constexpr int kDwLdsFloats = 14336; // 56 KiB of plane data per block (+ weights) -> 2 blocks per CU (depthwise_lds_scalar_kernel)
 
 // Direct 3x3 form: no LDS, every lane produces a VX-wide x R-high output patch straight from global memory.
 // Per input row it issues the aligned VX-wide centre vector(s) plus the two halo scalars (which hit lines its
@@ -460,71 +349,24 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     if (q.OH < 1 || q.OW < 1) return fail(FHIP_E_BADARG, "empty output");
 
     const int HW = q.H * q.W;
-    // the right-halo quad of the last group starts at (OW-4)*S + 4*S = OW*S: it is either inside the row or fully
-    // outside (zero); the centre quads need OW*S <= W.
-    const bool fast = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1 && (q.W % 4) == 0 &&
-                      (q.OW % 4) == 0 && q.OW * q.SW <= q.W && q.W >= 4 && HW + 12 <= kDwLdsFloats;
     StageTimer tm(FHIP_STAGE_DEPTHWISE, s);
-    // measurement switch: FHIP_DW_PATH=lds forces the LDS-staged kernels, =direct the no-LDS one (default: direct)
-    static const int dw_path = [] {
-        const char* e = getenv("FHIP_DW_PATH");
-        return (e && e[0] == 'l') ? 1 : 0;
-    }();
     const bool k3 = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1;
-    if (k3 && dw_path == 0)
+    if (k3)
     {
         const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
-        // rows per lane: 7 divides every MobileNet plane height (112 ... 7) and re-reads 9/7 input rows instead of 6/4
-        static const int r_env = [] {
-            const char* e = getenv("FHIP_DW_R");
-            return e ? atoi(e) : 0;
-        }();
-        const int R = q.SH == 1 ? ((r_env == 7 || r_env == 2 || r_env == 1) ? r_env : 4) : (r_env == 1 ? 1 : 2); // measured: R = 7 is 3-8 % slower than 4 except at 28x28
+        // output rows per lane: 4 at stride 1, 2 at stride 2 (measured against 1, 2 and 7: DESIGN.md 3.3)
+        const int R = q.SH == 1 ? 4 : 2;
         const int yblocks = ceil_div(q.OH, R), xvecs = q.OW / vx;
         const long long total = planes * yblocks * xvecs;
-        // grid-stride over at most 8192 blocks.  A plain copy is fastest with one float4 per thread and no loop
-        // (tools/copy_probe.hip: 6.2 TB/s vs 4.3-5.4 looped), but this kernel is not a plain copy: measured 1.14 ms per
-        // MobileNet step capped vs 1.21 ms with one item per lane (FHIP_DW_GRID=<blocks> changes the cap, 0 = uncapped)
-        static const long long grid_cap = [] {
-            const char* e = getenv("FHIP_DW_GRID");
-            return e ? atoll(e) : 8192LL;
-        }();
-        const long long blocks = (total + 255) / 256;
-        const int grid = (int)min(grid_cap > 0 ? grid_cap : (long long)0x7fffffff, blocks);
+        // grid-stride over at most 8192 blocks (measured optimum of 2048 ... 32768 and of "one item per lane")
+        const int grid = (int)min(8192LL, (total + 255) / 256);
 #define FHIP_DW_LAUNCH(S_, VX_, R_) \
     hipLaunchKernelGGL((depthwise3x3_direct_kernel<S_, VX_, R_>), dim3(grid), dim3(256), 0, s, q, yblocks, xvecs, total)
         if (q.SH == 1)
         {
-            if (R == 7)
-            {
-                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 7);
-                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 7);
-                else FHIP_DW_LAUNCH(1, 1, 7);
-            }
-            else if (R == 2)
-            {
-                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 2);
-                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 2);
-                else FHIP_DW_LAUNCH(1, 1, 2);
-            }
-            else if (R == 1)
-            {
-                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 1);
-                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 1);
-                else FHIP_DW_LAUNCH(1, 1, 1);
-            }
-            else
-            {
-                if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
-                else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
-                else FHIP_DW_LAUNCH(1, 1, 4);
-            }
-        }
-        else if (R == 1)
-        {
-            if (vx == 4) FHIP_DW_LAUNCH(2, 4, 1);
-            else if (vx == 2) FHIP_DW_LAUNCH(2, 2, 1);
-            else FHIP_DW_LAUNCH(2, 1, 1);
+            if (vx == 4) FHIP_DW_LAUNCH(1, 4, 4);
+            else if (vx == 2) FHIP_DW_LAUNCH(1, 2, 4);
+            else FHIP_DW_LAUNCH(1, 1, 4);
         }
         else
         {
@@ -533,17 +375,6 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
             else FHIP_DW_LAUNCH(2, 1, 2);
         }
 #undef FHIP_DW_LAUNCH
-    }
-    else if (fast)
-    {
-        q.planes_per_chunk = min(q.planes, kDwLdsFloats / (HW + 12));
-        const int chunks = ceil_div(q.planes, q.planes_per_chunk);
-        const size_t lds = (size_t)q.planes_per_chunk * (HW + 12) * sizeof(float);
-        const int grid = min(chunks, 256 * 8);
-        if (q.SH == 1)
-            hipLaunchKernelGGL(depthwise3x3_lds_kernel<1>, dim3(grid), dim3(256), lds, s, q);
-        else
-            hipLaunchKernelGGL(depthwise3x3_lds_kernel<2>, dim3(grid), dim3(256), lds, s, q);
     }
     else if (4 * (HW + q.KH * q.KW + 1) + 4 <= kDwLdsFloats)
     {

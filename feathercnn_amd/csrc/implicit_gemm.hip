@@ -20,7 +20,6 @@ using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
 // A 64x64 tile (GemmShape<64, 64, 16, 2, 2, 8>: 4x the blocks, 8 blocks per CU) was measured against split-K on ResNet-50's
 // under-filled layers and made no difference (C1024->K256 @14 b64: 0.093 vs 0.092 ms; C256->K64 @56: 0.077 vs 0.075): not kept.
-constexpr int kConvColTile = 128;
 
 static bool conv_small_m(int K) { return K <= 64; }
 // InnerProduct at small batch: with N <= 32 columns a 64-column tile spends half its MFMAs on padding, and fp32 MFMA is slow
@@ -48,13 +47,7 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     const int bm = (narrow || conv_small_m(p.output_channels)) ? 64 : 128, bn = narrow ? 32 : (conv_small_m(p.output_channels) ? 128 : 64);
     const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
     const int kt = kdp / kConvKTile;
-    // measurement switch: FHIP_IGEMM_SPLIT=S forces S (when it divides the k-tile count)
-    static const int forced = [] {
-        const char* e = getenv("FHIP_IGEMM_SPLIT");
-        return e ? atoi(e) : 0;
-    }();
     if (tiles >= 512 || kt < 16) return 1;
-    if (forced > 0) return std::min(forced, kt);
     int want;
     if (kt >= 512)
         // InnerProduct-like shapes (a handful of tiles, thousands of k-tiles: VGG fc6 is 64 narrow tiles x 1568) stream the weight
@@ -121,7 +114,7 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
 
 // ---- small-C convolutions (the first layer of every benchmark net: 3 input channels) ---------------------------------------
 // Measured against the generic gather (standalone, MI355X): VGG conv1_1 b32 0.158 vs 0.183 ms, ResNet conv1 b64 0.198 vs 0.271,
-// MobileNet conv1 b256 0.192 vs 0.276.  FHIP_SMALLC=0 disables it, FHIP_SMALLC_TW=16|32 forces the tile shape.
+// MobileNet conv1 b256 0.192 vs 0.276.
 // The generic gather above spends 4 scalar global loads + bounds checks per float4 of the column matrix and re-reads every
 // input pixel kh*kw times through L1.  Here a persistent block stages the whole weight matrix (C*kh*kw <= 160 rows) and, per
 // tile of 8 x 16 output pixels, the input patch ((8-1)*S+kh rows x (16-1)*S+kw columns x C) in LDS; the im2col gather then
@@ -313,12 +306,8 @@ static bool smallc_applicable(const fhip_conv_param& p)
     // larger one for s > k or kw > kh)
     const int tw = smallc_tile_w(p.output_w), th = 128 / tw;
     const int ph = (th - 1) * s + p.kernel_h, pw = (tw - 1) * s + p.kernel_w;
-    static const int off = [] {
-        const char* e = getenv("FHIP_SMALLC");
-        return (e && e[0] == '0') ? 1 : 0;
-    }(); // measurement switch: FHIP_SMALLC=0 falls back to the generic gather
     // output rows must take 16-byte stores: with scalar stores (SqueezeNet's 111-pixel rows) the generic kernel is faster
-    return !off && kd <= 160 && p.input_channels <= 8 && ph < 256 && pw < 256 && p.input_channels * ph * pw <= kSmallCMaxPatch &&
+    return kd <= 160 && p.input_channels <= 8 && ph < 256 && pw < 256 && p.input_channels * ph * pw <= kSmallCMaxPatch &&
            (p.output_w % 4) == 0;
 }
 

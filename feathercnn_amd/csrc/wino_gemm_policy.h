@@ -19,6 +19,7 @@ struct WinoGemmPolicy
         int C, K, Cp, Kp, Pp;
     };
     static __device__ int k_count(const Params& p, int) { return p.k_tiles; }
+    static __device__ float bias_at(const Params&, int) { return 0.f; } // the bias is the output transform's business
     struct ALoad
     {
         const float* base;
@@ -47,6 +48,7 @@ struct WinoGemmPolicy
         {
             if (m < p.K) *reinterpret_cast<float4*>(base + (size_t)m * p.Pp) = v; // Pp is a multiple of the column tile
         }
+        __device__ void put4b(const Params& p, int m, float4 v, float) const { put4(p, m, v); }
     };
 };
 

@@ -460,11 +460,7 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     {
         g.m_tiles = g.Kp / WinoShapeBig::BM;
         g.n_tiles = ceil_div(pl.columns, WinoShapeBig::BN);
-        static const int glds_off = [] {
-            const char* e = getenv("FHIP_WINO_GLDS");
-            return (e && e[0] == '0') ? 1 : 0;
-        }(); // measurement switch: FHIP_WINO_GLDS=0 runs the register-staged main loop of gemm_core.h
-        if (!glds_off && g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
+        if (g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
             hipLaunchKernelGGL(wino_gemm_glds_kernel<2>, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
         else
             hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),

@@ -171,6 +171,18 @@ def test_product_never_imports_oracle():
     assert proc.returncode == 0, proc.stderr
 
 
+def test_shipped_library_has_one_code_path_per_route():
+    """No algorithm switch behind an environment variable: libfeather_hip.so does not import getenv, and the product sources do not
+    mention it (the measurement variants live under tools/experiments and tools/*.hip)."""
+    from feathercnn_amd import _lib
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+    csrc = os.path.join(ROOT, "feathercnn_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_cpp_host_api_compiles_and_runs_like_convlayer(lib, tmp_path):
     """include/booster/booster.h is source-compatible with how feather::ConvLayer drives ConvBooster (conv_layer.h:92-172)."""
     from feathercnn_amd import _lib

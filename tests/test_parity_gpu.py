@@ -354,48 +354,6 @@ def test_forward_is_hipgraph_capturable(cuda, checker):
         assert nerr(o.cpu().numpy(), r) <= TOL
 
 
-_SWITCH_SCRIPT = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-import oracle
-from oracle import conv_geom, synth, nerr
-from feathercnn_amd import ConvLayer, ConvParam
-dev = torch.device("cuda:0")
-worst = 0.0
-# NB (24, 36): the REAL reference segfaults on ragged tiles when input_channels % 8 == 4 (e.g. 20->36 @19x19; probe in DESIGN.md)
-for g, n in [(conv_geom(24, 36, 19, 3, 1, 1), 5), (conv_geom(64, 64, 30, 3, 1, 1), 3), (conv_geom(16, 16, 28, 3, 1, 1, group=16), 3),
-             (conv_geom(16, 16, 28, 3, 2, 1, group=16), 3), (conv_geom(3, 24, 40, 7, 2, 3), 3), (conv_geom(3, 64, 36, 3, 1, 1, w=64), 2),
-             (conv_geom(4, 32, 33, 3, 2, 1, w=24), 2), (conv_geom(512, 64, 7, 1, 1, 0), 4)]:
-    x, w, b = synth(g, n, seed=4)
-    p = ConvParam(output_channels=g.oc, input_channels=g.ic, input_h=g.ih, input_w=g.iw, kernel_h=g.kh, kernel_w=g.kw, stride_h=g.sh,
-                  stride_w=g.sw, pad_left=g.pl, pad_right=g.pr, pad_top=g.pt, pad_bottom=g.pb, group=g.group, bias_term=True, activation=1, batch=n)
-    y = ConvLayer(p, torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)).Forward(torch.from_numpy(x).to(dev))
-    torch.cuda.synchronize()
-    worst = max(worst, nerr(y.cpu().numpy(), oracle.best().forward(g, x, w, b)))
-print("WORST", worst)
-assert worst <= 1e-4
-"""
-
-
-@pytest.mark.parametrize("env", [{"FHIP_WINO_FUSED": "1"}, {"FHIP_WINO_OVERLAP": "2"}, {"FHIP_WINO_OVERLAP": "3"}, {"FHIP_DW_PATH": "lds"},
-                                 {"FHIP_DW_R": "7"}, {"FHIP_DW_R": "2", "FHIP_DW_GRID": "0"}, {"FHIP_SMALLC": "0"}, {"FHIP_SMALLC_TW": "16"},
-                                 {"FHIP_SMALLC_TW": "32"}, {"FHIP_IGEMM_SPLIT": "4"}, {"FHIP_WINO_GLDS": "0"}], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-def test_measurement_switch_paths_stay_correct(env, cuda, tmp_path):
-    """The alternative kernels kept behind environment switches (fused Winograd GEMM+output, two-stream sub-batch pipeline,
-    LDS-staged depthwise, other depthwise patch heights / uncapped grid, generic gather instead of the small-C kernel and its two tile
-    shapes, forced split-K) are slower, not wrong: each is read once per process, so each runs in its own."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "switch.py"
-    script.write_text(_SWITCH_SCRIPT)
-    e = dict(os.environ)
-    e.update(env)
-    out = subprocess.run([sys.executable, str(script), root], env=e, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout + out.stderr
-
-
 @pytest.mark.parametrize("g,batch", [(conv_geom(20, 36, 19, 3, 1, 1), 3), (conv_geom(4, 4, 19, 3, 1, 1), 2), (conv_geom(20, 32, 25, 3, 1, 1), 2)],
                          ids=["20x36@19", "4x4@19", "20x32@25"])
 def test_winograd_shapes_the_reference_crashes_on(g, batch, cuda, port):

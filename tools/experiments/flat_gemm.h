@@ -20,10 +20,10 @@
 //     stage s's loads -- the loads of the stages behind it plus the accumulator stores of tile epilogues in that window;
 //   * raw s_barrier (a __syncthreads() would drain the DMA queue), one per stage: RAW (every wave's pieces of stage s landed)
 //     and WAR (the stage refilled next was read by all waves in the previous iteration) in one;
-//   * no VGPR-destination global load inside the loop (hipcc answers one with vmcnt(0), which would drain the ring): the bias
-//     of the block's rows is staged in LDS before the first request;
-//   * accumulators leave through a wave-private 16 x 36 LDS transpose as 16-byte row stores (gemm_core.h's epilogue in two
-//     half-tile passes: the smaller scratch is what lets three blocks share a CU).
+//   * no VGPR-destination global load inside the loop (hipcc answers one with vmcnt(0), which would drain the ring): the lane's
+//     bias values are requested right behind the prologue's operand requests and waited for once, ahead of the loop;
+//   * accumulators leave straight from the MFMA registers as 16-byte stores (operand roles swapped, see the kernel): no LDS
+//     scratch, so the ring is all the LDS a block needs.
 #pragma once
 
 #include "common.h"
@@ -44,9 +44,7 @@ struct FlatShape
     static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     static constexpr int TM = WTM / 32, TN = WTN / 32;
     static constexpr int STAGE = BK * (BM + BN); // floats
-    static constexpr int EPI_LD = 36;
-    static constexpr int EPI = 4 * 16 * EPI_LD; // one 16-row transpose scratch per wave
-    static constexpr int LDS_FLOATS = D * STAGE + EPI + BM; // ring | scratch | bias of the block's rows
+    static constexpr int LDS_FLOATS = D * STAGE; // the ring (wave_gemm.h adds its own scratch)
     static constexpr int S = TM * TN * 4;        // 16-byte stores per lane and output tile
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % 64 == 0 && BN % 16 == 0, "tile shape");
@@ -70,6 +68,14 @@ __device__ __forceinline__ void flat_wait(int n)
     }
 }
 
+// measurement builds only (ABLATE bit 3): every 64th block adds its shader-clock and 100 MHz wall-clock ticks here, which gives the
+// effective shader clock the kernel really ran at (the chip clocks to its power budget)
+static __device__ unsigned long long g_flat_clock_probe[2];
+
+// measurement builds only (ABLATE bit 5): shader-clock stamps of sampled blocks: [sample][wave][16] = start, ring primed, after the
+// wait / barrier / MFMAs of the first stages, end
+static __device__ long long g_flat_timeline[64][4][16];
+
 // one wave-wide LDS-DMA request: 64 lanes x VEC floats from per-lane global addresses to `dst` + lane * VEC (dst wave-uniform)
 template <int VEC>
 __device__ __forceinline__ void flat_request(const float* src, float* dst)
@@ -88,17 +94,35 @@ __device__ __forceinline__ void flat_request(const float* src, float* dst)
 //   const float* bias(p), int rows(p), int cols(p)   bias vector or nullptr, number of real output rows / columns
 //   struct Out { Out(p, batch, n4); void put4(p, m, v, bias_m) }   4 consecutive output columns of row m
 // ABLATE (measurement builds only, tools/flat_bench.hip; the product always uses 0): bit 0 = every tile re-requests the block's FIRST
-// B tile (no new HBM reads), bit 1 = no accumulator stores, bit 2 = no MFMAs.
+// B tile (no new HBM reads), bit 1 = no accumulator stores, bit 2 = no MFMAs, bit 3 = clock probe, bit 4 = no operand requests
+// after the prologue (the loop reads stale LDS: pure LDS + MFMA + synchronisation), bit 5 = timeline stamps.
+//
+// Epilogue (round-2 timeline probe: the LDS-transposed epilogue of gemm_core.h costs ~3400 cycles of serialised LDS round trips
+// per tile, and a bias fetched ahead of the first operand request adds a whole memory round trip to every block): the MFMA is
+// issued with the operand ROLES SWAPPED -- the B-tile fragment as srcA, the A-tile fragment as srcB -- so the accumulator is the
+// transposed 32 x 32 piece: lane l holds row m = l & 31 and, per register quad g, the four CONSECUTIVE columns
+// n = 8g + 4 (l >> 5) .. +3.  A quad is one 16-byte store straight into the output row: no LDS scratch, no transpose, and the
+// lane's bias is one value per 32-row piece, loaded after the ring is primed and first used after the k-loop.
 template <class Shape, class Policy, int ABLATE = 0>
 __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typename Policy::Params prm)
 {
-    constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK, D = Shape::D, STAGE = Shape::STAGE, EPI_LD = Shape::EPI_LD;
+    constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK, D = Shape::D, STAGE = Shape::STAGE;
     constexpr int VEC = Policy::VEC;
     constexpr int GA = BK * BM / 256 / 4;                         // A requests per wave and stage (16-byte lanes)
     constexpr int B_PIECES = BK * BN / (64 * VEC);                // wave-wide B requests per stage
     constexpr int GB = (B_PIECES + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float lds[Shape::LDS_FLOATS]; // ONE LDS object (a second one de-pipelines hipcc's waits)
-    float* const bias_s = lds + D * STAGE + Shape::EPI;
+    __shared__ __attribute__((aligned(16))) float lds[D * STAGE]; // ONE LDS object (a second one de-pipelines hipcc's waits)
+
+    const long long probe_c0 = (ABLATE & 8) ? clock64() : 0, probe_w0 = (ABLATE & 8) ? wall_clock64() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool tl_on = (ABLATE & 32) && (blockIdx.x % 97) == 5 && blockIdx.x / 97 < 64;
+    long long* const tl = tl_on ? &g_flat_timeline[blockIdx.x / 97][wave][0] : nullptr;
+    int tl_n = 0;
+    auto stamp = [&]() {
+        if ((ABLATE & 32) && tl_on && lane == 0 && tl_n < 16) tl[tl_n] = clock64();
+        ++tl_n;
+    };
+    stamp();
 
     const int n_groups = (prm.n_tiles + prm.tpb - 1) / prm.tpb;
     const int nwg = prm.batches * prm.m_tiles * n_groups;
@@ -113,15 +137,8 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
     const int k_tiles = prm.k_tiles;
     const int total = ntl * k_tiles;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Shape::WAVES_N, wn = wave % Shape::WAVES_N;
     const int l31 = lane & 31, half = lane >> 5;
-
-    // bias of the block's rows -> LDS, BEFORE the first LDS-DMA request (an ordinary load later would drain the ring)
-    {
-        const float* bp = Policy::bias(prm);
-        if (tid < BM) bias_s[tid] = (bp && m0 + tid < Policy::rows(prm)) ? bp[m0 + tid] : 0.f;
-    }
 
     // ---- what this lane requests in every stage (invariant: position inside the stage image)
     const float* a_src[GA];
@@ -149,13 +166,6 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
 #pragma unroll
         for (int g = 0; g < GB; ++g) b_src[g] = Policy::b_ptr(prm, batch, (t0 + ((ABLATE & 1) ? 0 : t)) * BN + b_col[g]);
     };
-    f32x16 acc[Shape::TM][Shape::TN];
-#pragma unroll
-    for (int i = 0; i < Shape::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < Shape::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // issue side of the flat sequence
     int it_i = 0, kt_i = 0, buf_i = 0;
@@ -163,15 +173,13 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
     auto issue_next = [&]() {
         float* base = lds + buf_i * STAGE;
 #pragma unroll
-        for (int g = 0; g < GA; ++g)
-            flat_request<4>(a_src[g] + (size_t)kt_i * a_step, base + (wave + 4 * g) * 256);
+        for (int g = 0; g < GA; ++g) flat_request<4>(a_src[g] + (size_t)kt_i * a_step, base + (wave + 4 * g) * 256);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
             if (wave + 4 * g < B_PIECES)
             {
                 const int r = min(kt_i * BK + b_row[g], krows - 1);
-                const float* src = b_src[g] + (size_t)r * ldb;
-                flat_request<VEC>(src, base + BK * BM + (wave + 4 * g) * (64 * VEC));
+                flat_request<VEC>(b_src[g] + (size_t)r * ldb, base + BK * BM + (wave + 4 * g) * (64 * VEC));
             }
         buf_i = buf_i + 1 == D ? 0 : buf_i + 1;
         if (++kt_i == k_tiles)
@@ -183,15 +191,39 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
 #pragma unroll
     for (int f = 0; f < D - 1; ++f)
         if (f < total) issue_next();
+    stamp(); // ring primed (requests issued)
+
+    // the lane's bias values: requested BEHIND the first operand requests, first used after a whole k-loop
+    const int out_rows = Policy::rows(prm), out_cols = Policy::cols(prm);
+    float bv[Shape::TM];
+    {
+        const float* bp = Policy::bias(prm);
+#pragma unroll
+        for (int i = 0; i < Shape::TM; ++i)
+        {
+            const int m = m0 + wm * Shape::WTM + i * 32 + l31;
+            bv[i] = bp ? bp[min(m, out_rows - 1)] : 0.f;
+        }
+    }
+
+    f32x16 acc[Shape::TM][Shape::TN];
+#pragma unroll
+    for (int i = 0; i < Shape::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Shape::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int a_off = half * BM + wm * Shape::WTM + l31;
     const int b_off = BK * BM + half * BN + wn * Shape::WTN + l31;
-    float* const scr = lds + D * STAGE + wave * (16 * EPI_LD);
-    const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
-
     // wave-uniform copies for the store bookkeeping (SGPRs: the conditions below become scalar branches)
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
-    const int out_rows = Policy::rows(prm), out_cols = Policy::cols(prm);
+
+    // Consume the bias registers HERE: hipcc places its s_waitcnt vmcnt(0) for them in front of this statement -- once, ahead of the
+    // loop, where it only waits for the prologue's stages -- instead of in front of their first use in the epilogue, where it
+    // would drain the ring at every tile.
+#pragma unroll
+    for (int i = 0; i < Shape::TM; ++i) asm volatile("" ::"v"(bv[i]));
 
     int cur = 0, kt = 0, it = 0;
     int hist[D - 1]; // hist[i]: store instructions this wave issued in iteration s-1-i (they sit behind the loads we wait for)
@@ -202,13 +234,16 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
         // Operations issued after stage s's loads: the loads of the `later` stages behind it and the epilogue stores of the last
         // D-1 iterations.  The count must never be ABOVE the truth (that would under-wait); every store counted below is issued
         // under a wave-uniform condition with at least one active lane, so it is a lower bound (exact for 16-byte stores).
+        // (The bias loads of the prologue sit behind the prologue's stages too: the first D-1 waits are stricter by TM.  Safe.)
         const int later = min(total - 1 - s, D - 2);
         int behind = later * gw;
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) behind += hist[i];
         flat_wait(behind);
+        if (s < 4) stamp(); // my pieces landed
         __builtin_amdgcn_s_barrier();
-        if (s + D - 1 < total) issue_next();
+        if (s < 4) stamp(); // everybody's pieces landed
+        if (s + D - 1 < total && !(ABLATE & 16)) issue_next();
 
         const float* as = lds + cur * STAGE + a_off;
         const float* bs = lds + cur * STAGE + b_off;
@@ -224,55 +259,49 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
             for (int i = 0; i < Shape::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Shape::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j], fa[i], acc[i][j], 0, 0, 0); // roles swapped: acc = (A B)^T piece
         }
+        if (s < 4) stamp(); // MFMAs issued
 
         int stores = 0;
         const bool end = kt == k_tiles - 1;
         if (end)
         {
-            // ---- tile epilogue: per-wave LDS transpose (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)),
-            // two half-tile passes, 16-byte row stores.  Wave-private scratch + in-order LDS queue: no barrier.
+            // ---- tile epilogue: acc[i][j][4g + e] = out[m = .. + i*32 + l31][n = .. + j*32 + 8g + 4*half + e]
             const int n0 = (t0 + it) * BN;
 #pragma unroll
             for (int j = 0; j < Shape::TN; ++j)
-            {
-                const int nj = n0 + wn_u * Shape::WTN + j * 32; // first column of this 32-column piece (wave-uniform)
-                const typename Policy::Out st(prm, batch, nj + e_c4);
 #pragma unroll
-                for (int i = 0; i < Shape::TM; ++i)
+                for (int g = 0; g < 4; ++g)
                 {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    const int nq = n0 + wn_u * Shape::WTN + j * 32 + 8 * g; // first column of this instruction's 8 (wave-uniform)
+                    if (nq < out_cols)
                     {
+                        const typename Policy::Out st(prm, batch, nq + 4 * half);
 #pragma unroll
-                        for (int r = 0; r < 8; ++r)
-                            scr[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[i][j][8 * h + r];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
+                        for (int i = 0; i < Shape::TM; ++i)
                         {
-                            const int mq = wm_u * Shape::WTM + i * 32 + h * 16 + q * 8; // first of the 8 rows this instruction stores
-                            if (nj < out_cols && m0 + mq < out_rows)                  // wave-uniform: lane (row 0, column 0) is active
+                            const int mi = m0 + wm_u * Shape::WTM + i * 32; // first row of this instruction's 32 (wave-uniform)
+                            if (mi < out_rows)
                             {
-                                // four float reads, not one float4 read: hipcc (ROCm 7.2) answers a type-punned LDS read next to an
-                                // in-flight LDS-DMA with s_waitcnt vmcnt(0) -- which would drain the ring at every tile -- but
-                                // not a float read (it merges the four into one ds_read_b128 anyway)
-                                const float* sp = &scr[(q * 8 + e_row) * EPI_LD + e_c4];
-                                const float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                                const float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                                 if (ABLATE & 2)
                                     asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                                 else
                                 {
-                                    st.put4(prm, m0 + mq + e_row, v, bias_s[mq + e_row]);
+                                    st.put4(prm, mi + l31, v, bv[i]);
                                     ++stores;
                                 }
                             }
                         }
                     }
+                }
+#pragma unroll
+            for (int i = 0; i < Shape::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Shape::TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                }
-            }
             ++it;
             kt = 0;
         }
@@ -282,6 +311,12 @@ __global__ __launch_bounds__(256, Shape::OCC) void flat_gemm_kernel(const typena
         for (int i = D - 2; i > 0; --i) hist[i] = hist[i - 1];
         hist[0] = stores;
         cur = cur + 1 == D ? 0 : cur + 1;
+    }
+    if ((ABLATE & 32) && tl_on && lane == 0) tl[15] = clock64();
+    if ((ABLATE & 8) && threadIdx.x == 0 && (blockIdx.x & 63) == 0)
+    {
+        atomicAdd(&g_flat_clock_probe[0], (unsigned long long)(clock64() - probe_c0));
+        atomicAdd(&g_flat_clock_probe[1], (unsigned long long)(wall_clock64() - probe_w0));
     }
 }
 

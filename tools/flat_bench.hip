@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "flat_gemm.h"
+#include "wave_gemm.h"
+#include "conv_gemm_policy.h"
 
 using namespace fhip;
 
@@ -66,11 +68,20 @@ static void fill_random(float* d, size_t n, unsigned seed, float scale)
     for (size_t off = 0; off < n; off += h.size()) CK(hipMemcpy(d + off, h.data(), std::min(h.size(), n - off) * 4, hipMemcpyHostToDevice));
 }
 
+static double read_clock_mhz()
+{
+    unsigned long long h[2] = {0, 0}, z[2] = {0, 0};
+    CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_flat_clock_probe), sizeof h));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_flat_clock_probe), z, sizeof z));
+    return h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+}
+
 struct Result
 {
     std::string name;
     std::vector<double> ms;
     double diff = 0;
+    double mhz = 0;
 };
 
 static double median(std::vector<double> v)
@@ -112,6 +123,54 @@ static void launch_flat_conv(const FlatConvParams& g0, int tpb)
     g.batches = 1;
     const int groups = (g.n_tiles + tpb - 1) / tpb;
     hipLaunchKernelGGL((flat_gemm_kernel<Shape, FlatConvPolicy<VEC>, ABL>), dim3(g.m_tiles * groups), dim3(256), 0, 0, g);
+}
+
+template <class Shape, int VEC, int ABL = 0>
+static void launch_wave_conv(const FlatConvParams& g0, int tpb)
+{
+    FlatConvParams g = g0;
+    g.m_tiles = (g.K + 63) / 64;
+    g.n_tiles = (g.Ntot + 63) / 64;
+    g.tpb = tpb;
+    g.batches = 1;
+    const int groups = (g.n_tiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL((wave_gemm_kernel<Shape, FlatConvPolicy<VEC>, ABL>), dim3(g.m_tiles * groups), dim3(64), 0, 0, g);
+}
+
+// the product's register-staged kernel (gemm_core.h + conv_gemm_policy.h) instantiated here with other occupancies / stamps
+template <class Shape, int MODE, int ABL = 0, int TUNE = 3>
+static void launch_core_conv(const FlatConvParams& f, const float* in, float* out, const float* bias)
+{
+    ConvGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.batches = 1;
+    g.Wt = f.Wt;
+    g.in = in;
+    g.out = out;
+    g.bias = bias;
+    g.C = f.C;
+    g.K = f.K;
+    g.H = g.W = f.W;
+    g.OH = f.OHW / f.OW;
+    g.OW = f.OW;
+    g.SH = f.SH;
+    g.SW = f.SW;
+    g.KH = g.KW = 1;
+    g.Kd = f.C;
+    g.Kp = (f.K + f.bm - 1) / f.bm * f.bm;
+    g.Kdp = f.Kdp;
+    g.bm = f.bm;
+    g.Ntot = f.Ntot;
+    g.OHW = f.OHW;
+    g.HW = f.HWin;
+    g.KHW = 1;
+    g.has_bias = 1;
+    g.relu = 1;
+    g.split_k = 1;
+    g.k_tiles = f.Kdp / 16;
+    g.m_tiles = g.Kp / Shape::BM;
+    g.n_tiles = (g.Ntot + Shape::BN - 1) / Shape::BN;
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>, ABL, TUNE>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
 }
 
 static void run_conv(const ConvCase& cs, int rounds)
@@ -171,12 +230,12 @@ static void run_conv(const ConvCase& cs, int rounds)
                         if (vec4) launch_flat_conv<SHAPE, 4>(g, TPB);                               \
                         else launch_flat_conv<SHAPE, 1>(g, TPB);                                    \
                     }})
-    using S128x64d3 = FlatShape<128, 64, 2, 2, 3, 3>;
-    using S128x64d4 = FlatShape<128, 64, 2, 2, 4, 2>;
-    using S128x128d3 = FlatShape<128, 128, 2, 2, 3, 2>;
-    using S64x128d3 = FlatShape<64, 128, 1, 4, 3, 3>;
-    using S64x128d4 = FlatShape<64, 128, 1, 4, 4, 2>;
-    using S64x64d4 = FlatShape<64, 64, 2, 2, 4, 3>;
+    using S128x64d3 = FlatShape<128, 64, 2, 2, 3, 4>;
+    using S128x64d4 = FlatShape<128, 64, 2, 2, 4, 3>;
+    using S128x128d3 = FlatShape<128, 128, 2, 2, 3, 3>;
+    using S64x128d3 = FlatShape<64, 128, 1, 4, 3, 4>;
+    using S64x128d4 = FlatShape<64, 128, 1, 4, 4, 3>;
+    using S64x64d4 = FlatShape<64, 64, 2, 2, 4, 4>;
     if (cs.K > 64)
     {
         V("flat 128x64 D3 tpb1", S128x64d3, 1);
@@ -200,6 +259,113 @@ static void run_conv(const ConvCase& cs, int rounds)
         V("flat 64x64 D4 tpb8", S64x64d4, 8);
     }
 #undef V
+    if (getenv("FLAT_WAVE"))
+    {
+        vars.resize(1);
+#define VW(NAME, SHAPE, TPB)                                                                        \
+    vars.push_back({NAME, [&, g] {                                                                  \
+                        if (vec4) launch_wave_conv<SHAPE, 4>(g, TPB);                               \
+                        else launch_wave_conv<SHAPE, 1>(g, TPB);                                    \
+                    }})
+        using W16d2 = WaveShape<16, 2, 2>;
+        using W16d3 = WaveShape<16, 3, 2>;
+        using W8d2 = WaveShape<8, 2, 2>;
+        using W8d3 = WaveShape<8, 3, 2>;
+        using W8d4 = WaveShape<8, 4, 2>;
+        VW("wave BK16 D2 tpb1", W16d2, 1);
+        VW("wave BK16 D2 tpb2", W16d2, 2);
+        VW("wave BK16 D2 tpb4", W16d2, 4);
+        VW("wave BK16 D2 tpb8", W16d2, 8);
+        VW("wave BK16 D3 tpb2", W16d3, 2);
+        VW("wave BK8 D2 tpb1", W8d2, 1);
+        VW("wave BK8 D2 tpb4", W8d2, 4);
+        VW("wave BK8 D3 tpb1", W8d3, 1);
+        VW("wave BK8 D3 tpb2", W8d3, 2);
+        VW("wave BK8 D3 tpb4", W8d3, 4);
+        VW("wave BK8 D3 tpb8", W8d3, 8);
+        VW("wave BK8 D4 tpb4", W8d4, 4);
+        if (vec4)
+        {
+            vars.push_back({"wave BK8 D3 tpb4 noread+nostore", [&, g] { launch_wave_conv<W8d3, 4, 3>(g, 4); }});
+            vars.push_back({"wave BK16 D2 tpb4 noread+nostore", [&, g] { launch_wave_conv<W16d2, 4, 3>(g, 4); }});
+            vars.push_back({"wave BK8 D3 tpb4 noMFMA", [&, g] { launch_wave_conv<W8d3, 4, 4>(g, 4); }});
+        }
+#undef VW
+    }
+    if (getenv("FLAT_CORE") && vec4 && cs.K > 64)
+    {
+        vars.resize(1);
+        using C4 = GemmShape<128, 64, 16, 2, 2, 4>;
+        using C6 = GemmShape<128, 64, 16, 2, 2, 6>;
+        vars.push_back({"core 128x64 occ4 tune0 (r01)", [&, g] { launch_core_conv<C4, 2, 0, 0>(g, in, out, bias); }});
+        vars.push_back({"core 128x64 occ4 tune1 prio", [&, g] { launch_core_conv<C4, 2, 0, 1>(g, in, out, bias); }});
+        vars.push_back({"core 128x64 occ4 tune2 bias", [&, g] { launch_core_conv<C4, 2, 0, 2>(g, in, out, bias); }});
+        vars.push_back({"core 128x64 occ4 tune3", [&, g] { launch_core_conv<C4, 2, 0, 3>(g, in, out, bias); }});
+        vars.push_back({"core 128x64 occ6 tune3", [&, g] { launch_core_conv<C6, 2, 0, 3>(g, in, out, bias); }});
+        vars.push_back({"core 64x64 occ8 tune3", [&, g] { launch_core_conv<GemmShape<64, 64, 16, 2, 2, 8>, 2, 0, 3>(g, in, out, bias); }});
+        vars.push_back({"core 128x128 occ3 tune3", [&, g] { launch_core_conv<GemmShape<128, 128, 16, 2, 2, 3>, 2, 0, 3>(g, in, out, bias); }});
+        static long long zero[64][16];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_core_timeline), zero, sizeof zero));
+        launch_core_conv<GemmShape<128, 64, 16, 2, 2, 4>, 2>(g, in, out, bias);
+        launch_core_conv<GemmShape<128, 64, 16, 2, 2, 4>, 2>(g, in, out, bias);
+        CK(hipDeviceSynchronize());
+        launch_core_conv<GemmShape<128, 64, 16, 2, 2, 4>, 2, 32, 3>(g, in, out, bias);
+        CK(hipDeviceSynchronize());
+        static long long tl[64][16];
+        CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_core_timeline), sizeof tl));
+        printf("core timeline %s (k_tiles %d): cycles since block start at [setup | k-tile 0 in LDS | after k-tiles 0..3 | k-loop done | store desc | transpose written | 4 stores | end]\n", cs.name, g.k_tiles);
+        for (int b = 0; b < 64; b += 3)
+        {
+            if (!tl[b][0]) continue;
+            printf("  blk %5d :", b * 97 + 5);
+            for (int i : {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15}) printf(" %6lld", tl[b][i] ? tl[b][i] - tl[b][0] : -1);
+            printf("\n");
+        }
+    }
+    if (getenv("FLAT_TIMELINE") && vec4 && cs.K > 64)
+    {
+        // one launch of the flat kernel with stamps, dump the sampled blocks
+        static long long zero[64][4][16];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_flat_timeline), zero, sizeof zero));
+        launch_flat_conv<S128x64d3, 4, 0>(g, 1);
+        launch_flat_conv<S128x64d3, 4, 0>(g, 1);
+        CK(hipDeviceSynchronize());
+        launch_flat_conv<S128x64d3, 4, 32>(g, 1);
+        CK(hipDeviceSynchronize());
+        static long long tl[64][4][16];
+        CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_flat_timeline), sizeof tl));
+        printf("timeline %s (k_tiles %d): per sampled block, wave 0: cycles since block start at [primed | s0: landed, barrier, mfma | s1: ... | end]\n", cs.name, g.k_tiles);
+        long long base0 = 0;
+        for (int b = 0; b < 64; ++b)
+        {
+            if (!tl[b][0][0]) continue;
+            if (!base0) base0 = tl[b][0][0];
+            printf("  blk %5d start@%8lld :", b * 97 + 5, tl[b][0][0] - base0);
+            for (int i = 1; i < 14; ++i) printf(" %6lld", tl[b][0][i] ? tl[b][0][i] - tl[b][0][0] : -1);
+            printf(" | end %6lld | waves end: %lld %lld %lld\n", tl[b][0][15] - tl[b][0][0], tl[b][1][15] - tl[b][0][0], tl[b][2][15] - tl[b][0][0], tl[b][3][15] - tl[b][0][0]);
+        }
+    }
+    if (getenv("FLAT_CLK") && vec4)
+    {
+        vars.resize(1);
+        if (cs.K > 64)
+        {
+            vars.push_back({"flat 128x64 D3 tpb1 +clk", [&, g] { launch_flat_conv<S128x64d3, 4, 8>(g, 1); }});
+            vars.push_back({"flat 128x128 D3 tpb1 +clk", [&, g] { launch_flat_conv<S128x128d3, 4, 8>(g, 1); }});
+        }
+        else
+            vars.push_back({"flat 64x128 D3 tpb1 +clk", [&, g] { launch_flat_conv<S64x128d3, 4, 8>(g, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk", [&, g] { launch_wave_conv<WaveShape<16, 2, 2>, 4, 8>(g, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk noread+nostore", [&, g] { launch_wave_conv<WaveShape<16, 2, 2>, 4, 11>(g, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk noMFMA", [&, g] { launch_wave_conv<WaveShape<16, 2, 2>, 4, 12>(g, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk norequests+nostore", [&, g] { launch_wave_conv<WaveShape<16, 2, 2>, 4, 26>(g, 1); }});
+        if (cs.K > 64)
+        {
+            vars.push_back({"flat 128x64 D3 tpb1 +clk norequests+nostore", [&, g] { launch_flat_conv<S128x64d3, 4, 26>(g, 1); }});
+            vars.push_back({"flat 128x128 D3 tpb1 +clk norequests+nostore", [&, g] { launch_flat_conv<S128x128d3, 4, 26>(g, 1); }});
+            vars.push_back({"flat 128x64 D3 tpb1 +clk noread+nostore", [&, g] { launch_flat_conv<S128x64d3, 4, 11>(g, 1); }});
+        }
+    }
     if (getenv("FLAT_ABLATE") && vec4)
     {
         vars.resize(1);
@@ -235,18 +401,22 @@ static void run_conv(const ConvCase& cs, int rounds)
            cs.S, cs.N, g.Ntot, flops / 1e9, bytes / 1e6, flops / 157.3e6, bytes / 5e6, vec4 ? "" : "  [dword gathers]");
     std::vector<Result> res(vars.size());
     for (int r = 0; r < rounds; ++r)
-        for (size_t v = 0; v < vars.size(); ++v)
+        for (size_t vv = 0; vv < vars.size(); ++vv)
         {
+            const size_t v = r == 0 ? vv : (vv + (size_t)r * 3) % vars.size(); // round 0 in order (the reference first), then rotated
             res[v].name = vars[v].first;
             if (r == 0 && v > 0) CK(hipMemset(out, 0xff, out_n * 4));
             res[v].ms.push_back(time_ms(vars[v].second));
+            { const double c = read_clock_mhz(); if (c > 0) res[v].mhz = c; }
             if (r == 0 && v > 0) res[v].diff = compare(out, out_ref, out_n);
         }
     for (auto& r : res)
     {
         const double ms = median(r.ms), best = *std::min_element(r.ms.begin(), r.ms.end());
-        printf("   %-24s %8.4f ms (best %8.4f)  %7.2f TF  %5.1f%%   diff %.1e%s\n", r.name.c_str(), ms, best, flops / ms / 1e9,
-               flops / ms / 1e9 / 157.3 * 100, r.diff, (r.diff > 1e-5 && !getenv("FLAT_ABLATE")) ? "  !!WRONG" : "");
+        printf("   %-24s %8.4f ms (best %8.4f)  %7.2f TF  %5.1f%%   diff %.1e%s", r.name.c_str(), ms, best, flops / ms / 1e9,
+               flops / ms / 1e9 / 157.3 * 100, r.diff, (r.diff > 1e-5 && r.name.find("no") == std::string::npos) ? "  !!WRONG" : "");
+        if (r.mhz > 0) printf("   shader clock %.0f MHz -> %.1f%% of the MFMA rate at that clock", r.mhz, flops / ms / 1e9 / (157.3 * r.mhz / 2400.0) * 100);
+        printf("\n");
     }
     fflush(stdout);
     (void)hipFree(in);
@@ -265,7 +435,7 @@ struct WinoCase
     int C, K, H, N; // 3x3 s1 p1 convolution on H x H images
 };
 
-template <class Shape>
+template <class Shape, int ABL = 0>
 static void launch_flat_wino(const FlatWinoParams& g0, int P, int tpb)
 {
     FlatWinoParams g = g0;
@@ -274,7 +444,19 @@ static void launch_flat_wino(const FlatWinoParams& g0, int P, int tpb)
     g.tpb = tpb;
     g.batches = 64;
     const int groups = (g.n_tiles + tpb - 1) / tpb;
-    hipLaunchKernelGGL((flat_gemm_kernel<Shape, FlatWinoPolicy>), dim3(64 * g.m_tiles * groups), dim3(256), 0, 0, g);
+    hipLaunchKernelGGL((flat_gemm_kernel<Shape, FlatWinoPolicy, ABL>), dim3(64 * g.m_tiles * groups), dim3(256), 0, 0, g);
+}
+
+template <class Shape, int ABL = 0>
+static void launch_wave_wino(const FlatWinoParams& g0, int P, int tpb)
+{
+    FlatWinoParams g = g0;
+    g.m_tiles = (g.K + 63) / 64;
+    g.n_tiles = (P + 63) / 64;
+    g.tpb = tpb;
+    g.batches = 64;
+    const int groups = (g.n_tiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL((wave_gemm_kernel<Shape, FlatWinoPolicy, ABL>), dim3(64 * g.m_tiles * groups), dim3(64), 0, 0, g);
 }
 
 static void run_wino(const WinoCase& cs, int rounds)
@@ -294,13 +476,17 @@ static void run_wino(const WinoCase& cs, int rounds)
     fhip_winograd_plan pl;
     CF(fhip_winograd_f63_plan(&p, cs.N, &pl));
     float *U, *V, *M, *Mref, *w;
+    // FLAT_PP=<columns>: the flat / wave variants use this row pitch for V and M instead of the product's (does the pitch matter?)
+    const int pp_override = getenv("FLAT_PP") ? atoi(getenv("FLAT_PP")) : 0;
+    if (pp_override && (pp_override < pl.columns || pp_override % 4)) { printf("bad FLAT_PP\n"); exit(1); }
+    const size_t pp_scale_num = pp_override > pl.columns_padded ? pp_override : pl.columns_padded;
     CK(hipMalloc(&U, pl.u_bytes));
-    CK(hipMalloc(&V, pl.v_bytes));
-    CK(hipMalloc(&M, pl.m_bytes));
+    CK(hipMalloc(&V, pl.v_bytes / pl.columns_padded * pp_scale_num));
+    CK(hipMalloc(&M, pl.m_bytes / pl.columns_padded * pp_scale_num));
     CK(hipMalloc(&Mref, pl.m_bytes));
     CK(hipMalloc(&w, (size_t)cs.K * cs.C * 9 * 4));
     fill_random(w, (size_t)cs.K * cs.C * 9, 5, 1.f / std::sqrt(9.f * cs.C));
-    fill_random(V, pl.v_bytes / 4, 6, 1.f);
+    fill_random(V, pl.v_bytes / 4 / pl.columns_padded * pp_scale_num, 6, 1.f);
     CF(fhip_winograd_f63_transform_kernel(&p, U, w, nullptr));
     CK(hipMemset(Mref, 0, pl.m_bytes));
     CK(hipDeviceSynchronize());
@@ -314,19 +500,19 @@ static void run_wino(const WinoCase& cs, int rounds)
     g.K = cs.K;
     g.Cp = pl.in_channels_padded;
     g.Kp = pl.out_channels_padded;
-    g.Pp = pl.columns_padded;
+    g.Pp = pp_override ? pp_override : pl.columns_padded;
     g.k_tiles = g.Cp / 16;
     const int P = pl.columns;
 
     std::vector<std::pair<std::string, std::function<void()>>> vars;
     vars.push_back({"product (C-ABI)", [&] { CF(fhip_winograd_f63_tile_gemm(&p, cs.N, Mref, U, V, nullptr)); }});
 #define V_(NAME, SHAPE, TPB) vars.push_back({NAME, [&, g] { launch_flat_wino<SHAPE>(g, P, TPB); }})
-    using S128x64d3 = FlatShape<128, 64, 2, 2, 3, 3>;
-    using S128x64d4 = FlatShape<128, 64, 2, 2, 4, 2>;
+    using S128x64d3 = FlatShape<128, 64, 2, 2, 3, 4>;
+    using S128x64d4 = FlatShape<128, 64, 2, 2, 4, 3>;
     using S128x96d3 = FlatShape<128, 96, 4, 1, 3, 3>;
-    using S128x128d3 = FlatShape<128, 128, 2, 2, 3, 2>;
-    using S64x128d3 = FlatShape<64, 128, 1, 4, 3, 3>;
-    using S64x128d4 = FlatShape<64, 128, 1, 4, 4, 2>;
+    using S128x128d3 = FlatShape<128, 128, 2, 2, 3, 3>;
+    using S64x128d3 = FlatShape<64, 128, 1, 4, 3, 4>;
+    using S64x128d4 = FlatShape<64, 128, 1, 4, 4, 3>;
     if (cs.K > 64)
     {
         V_("flat 128x64 D3 tpb1", S128x64d3, 1);
@@ -347,6 +533,39 @@ static void run_wino(const WinoCase& cs, int rounds)
         V_("flat 64x128 D4 tpb4", S64x128d4, 4);
     }
 #undef V_
+    if (getenv("FLAT_CLK"))
+    {
+        vars.resize(1);
+        if (cs.K > 64)
+        {
+            vars.push_back({"flat 128x64 D3 tpb1 +clk", [&, g] { launch_flat_wino<S128x64d3, 8>(g, P, 1); }});
+            vars.push_back({"flat 128x128 D3 tpb1 +clk", [&, g] { launch_flat_wino<S128x128d3, 8>(g, P, 1); }});
+            vars.push_back({"flat 128x64 D3 tpb1 +clk noread+nostore", [&, g] { launch_flat_wino<S128x64d3, 11>(g, P, 1); }});
+        }
+        else
+            vars.push_back({"flat 64x128 D3 tpb1 +clk", [&, g] { launch_flat_wino<S64x128d3, 8>(g, P, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk", [&, g] { launch_wave_wino<WaveShape<16, 2, 2>, 8>(g, P, 1); }});
+        vars.push_back({"wave BK16 D2 tpb1 +clk noread+nostore", [&, g] { launch_wave_wino<WaveShape<16, 2, 2>, 11>(g, P, 1); }});
+    }
+    else if (getenv("FLAT_WAVE"))
+    {
+        vars.resize(1);
+#define VW(NAME, SHAPE, TPB) vars.push_back({NAME, [&, g] { launch_wave_wino<SHAPE>(g, P, TPB); }})
+        using W16d2 = WaveShape<16, 2, 2>;
+        using W8d2 = WaveShape<8, 2, 2>;
+        using W8d3 = WaveShape<8, 3, 2>;
+        using W8d4 = WaveShape<8, 4, 2>;
+        VW("wave BK16 D2 tpb1", W16d2, 1);
+        VW("wave BK16 D2 tpb2", W16d2, 2);
+        VW("wave BK16 D2 tpb4", W16d2, 4);
+        VW("wave BK8 D2 tpb1", W8d2, 1);
+        VW("wave BK8 D2 tpb4", W8d2, 4);
+        VW("wave BK8 D3 tpb1", W8d3, 1);
+        VW("wave BK8 D3 tpb2", W8d3, 2);
+        VW("wave BK8 D3 tpb4", W8d3, 4);
+        VW("wave BK8 D4 tpb4", W8d4, 4);
+#undef VW
+    }
     const double flops = 2.0 * 64 * cs.K * cs.C * (double)P;
     const double bytes = 4.0 * 64 * ((double)cs.C + cs.K) * P;
     printf("wino %-14s C%4d K%4d H%3d N%3d  P %6d (Pp %6d)  %.2f GFLOP  %.1f MB  (peak %.1f us, 5 TB/s %.1f us)\n", cs.name, cs.C, cs.K, cs.H, cs.N,
@@ -374,18 +593,22 @@ static void run_wino(const WinoCase& cs, int rounds)
         return worst;
     };
     for (int r = 0; r < rounds; ++r)
-        for (size_t v = 0; v < vars.size(); ++v)
+        for (size_t vv = 0; vv < vars.size(); ++vv)
         {
+            const size_t v = r == 0 ? vv : (vv + (size_t)r * 3) % vars.size();
             res[v].name = vars[v].first;
             if (r == 0 && v > 0) CK(hipMemset(M, 0xff, pl.m_bytes));
             res[v].ms.push_back(time_ms(vars[v].second));
-            if (r == 0 && v > 0) res[v].diff = diff_vs_ref();
+            { const double c = read_clock_mhz(); if (c > 0) res[v].mhz = c; }
+            if (r == 0 && v > 0 && !pp_override) res[v].diff = diff_vs_ref();
         }
     for (auto& r : res)
     {
         const double ms = median(r.ms), best = *std::min_element(r.ms.begin(), r.ms.end());
-        printf("   %-24s %8.4f ms (best %8.4f)  %7.2f TF  %5.1f%%   diff %.1e%s\n", r.name.c_str(), ms, best, flops / ms / 1e9,
+        printf("   %-24s %8.4f ms (best %8.4f)  %7.2f TF  %5.1f%%   diff %.1e%s", r.name.c_str(), ms, best, flops / ms / 1e9,
                flops / ms / 1e9 / 157.3 * 100, r.diff, r.diff > 1e-5 ? "  !!WRONG" : "");
+        if (r.mhz > 0) printf("   shader clock %.0f MHz -> %.1f%% of the MFMA rate at that clock", r.mhz, flops / ms / 1e9 / (157.3 * r.mhz / 2400.0) * 100);
+        printf("\n");
     }
     fflush(stdout);
     (void)hipFree(U);

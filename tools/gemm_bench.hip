@@ -9,8 +9,6 @@
 
 #include "gemm_core.h"
 #include "wino_gemm_policy.h"
-#include "gemm_core_v0.h"
-#include "gemm_core_p3.h"
 #include "wino_gemm_glds.h"
 
 using namespace fhip;
@@ -62,9 +60,7 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     const int tiles = g.batches * g.m_tiles * g.n_tiles;
     dim3 grid(tiles);
     auto launch = [&]() {
-        if constexpr (V0 == 1)
-            hipLaunchKernelGGL((gemm_mfma_kernel_v0<Shape, WinoGemmPolicy, ABLATE, 2>), grid, dim3(Shape::THREADS), 0, 0, g);
-        else if constexpr (V0 == 3)
+        if constexpr (V0 == 3)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 4)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 5>), grid, dim3(256), 0, 0, g);
@@ -72,8 +68,6 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 6)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 3>), grid, dim3(256), 0, 0, g);
-        else if constexpr (V0 == 2)
-            hipLaunchKernelGGL((gemm_mfma_kernel_p3<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
         else
             hipLaunchKernelGGL((gemm_mfma_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
     };
@@ -162,9 +156,7 @@ int main(int argc, char** argv)
                 if ((size_t)c.C * round_up(c.P, 256) > maxV || (size_t)c.K * round_up(c.P, 256) > maxM) continue;
                 printf("kt %d, %d block(s) per CU\n", kt, bpc);
                 run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("product", c, U, V, M, reps);
-                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 2>("p3", c, U, V, M, reps);
                 run<GemmShape<128, 64, 16, 2, 2, 4>, 1>("no global fetch", c, U, V, M, reps);
-                run<GemmShape<128, 64, 16, 2, 2, 4>, 1, 2>("p3 no global fetch", c, U, V, M, reps);
             }
         return 0;
     }

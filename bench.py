@@ -1,25 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- images/s of the fp32 forward pass on MI355X, per the driver contract.
 
-A "step" is one forward pass of the benchmark network over one synthetic batch already resident in HBM.  Default
-workload = BASELINE.json configs[1]: VGG-16, batch 32 per GPU, fp32, 224x224.  Two modes:
+A "step" is one forward pass of a benchmark network over one synthetic batch already resident in HBM.
 
-  --mode net (default)  the WHOLE network through the feather::Net runtime (include/feather_hip/feather_net.h): every
-                        convolution through the ConvBooster hot path plus the layers between them (pooling, FC,
-                        softmax, BN/Scale, eltwise ...), chained, from a synthetic ncnn .param/.bin model.
-  --mode convstack      only the convolution layers, each through ConvBooster::Forward with bias + ReLU fused and its
-                        input re-drawn (not chained) -- the hot path in isolation, SURVEY.md 8(d).
-
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
-  python bench.py --net resnet50|mobilenet_v1|vgg16|squeezenet_v1.1 [--batch B] [--mode convstack] [--fusion 0|1|2]
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+      The headline `value` is BASELINE.json configs[1]: VGG-16, 32 images per GPU, fp32, 224x224, the whole network through the
+      feather::Net runtime (every convolution through the ConvBooster hot path plus the layers between them), timed exactly as the
+      contract says: W untimed steps, then K steps between barrier + synchronize, max over ranks; weak scaling at N > 1.
+      The SAME process then times the other nets BASELINE.json's metric names, with the same procedure, and reports them under
+      "nets" / "rooflines":  N = 1: ResNet-50 b64 (configs[2]), MobileNet-V1 b256 (configs[3]) and ResNet-50 with 512 images (the
+      one-GPU point of configs[4]);  N > 1: configs[4] itself -- ResNet-50, 512 images in total sharded over the ranks (strong
+      scaling) -- and its weak point (64 per GPU).
+  python bench.py --net resnet50|mobilenet_v1|vgg16|squeezenet_v1.1 [--batch B | --global-batch G] [--fusion 0|1|2]
+      Only that net (its images/s becomes `value`).
+  python bench.py --mode convstack [--net ...]
+      Only the convolution layers, each through ConvBooster::Forward with bias + ReLU fused and its input re-drawn (not chained).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     : the dominant kernel (tile GEMM on fp32 MFMA for VGG/ResNet, depthwise on HBM for MobileNet), achieved =
-                 algorithmic FLOPs (bytes) of all its launches in a step / their HIP-event durations, measured live;
-  cpu_baseline : the REAL reference (oracle/_ref, FeatherCNN's AVX2 path compiled from /root/reference) timed on this
-                 host's cores on a bounded sample (1 image through the same conv stack per process).
-Multi-GPU: the batch dimension is sharded (fixed per-GPU batch => weak scaling); raw weights are generated on rank 0
-and broadcast once over RCCL/xGMI, every rank runs its own Init; there is no steady-state collective.
+  roofline     : the dominant kernel of the headline net (Winograd tile GEMM on fp32 MFMA for VGG-16);
+  rooflines    : per net, every hot kernel priced against its roofline -- tile GEMM and 1x1 implicit GEMM (MFMA; the latter with
+                 ConvParam::GetFLOPS), depthwise and the Winograd input transform (HBM).  achieved = algorithmic FLOPs (bytes) of the
+                 kernel's launches in a step / their HIP-event durations on the launch stream, taken in eager passes of the same
+                 step right after the timed region (a replayed hipGraph cannot carry per-kernel events);  traffic = null: PMC
+                 counters cannot be read in-process, the rocprofv3 passes of this command are committed under profiles/;
+  cpu_baseline : the REAL reference runtime (oracle/_ref: FeatherCNN's feather::Net + AVX2 booster compiled from /root/reference)
+                 on this host, one single-thread process per core (its AVX Winograd is single-thread only), one image each.
+Multi-GPU: the batch dimension is sharded; the model is generated on rank 0 and its .bin broadcast once over RCCL/xGMI, every
+rank runs its own Init; there is no steady-state collective.
 """
 from __future__ import annotations
 
@@ -41,15 +48,16 @@ DEFAULT_BATCH = {"vgg16": 32, "resnet50": 64, "mobilenet_v1": 256, "squeezenet_v
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--net", default="vgg16", choices=list(DEFAULT_BATCH))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--net", default=None, choices=list(DEFAULT_BATCH), help="time ONLY this net (default: VGG-16 as the headline value, then ResNet-50 and MobileNet-V1 in the same process)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the additional nets of the default run")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE.json config)")
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (strong scaling, SURVEY.md 8d config 5: "
                     "--net resnet50 --global-batch 512 --gpus 8); rank r takes shard_range(global, r, N) images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay per step")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: all cores, max 64)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: one per host core, bounded by free memory)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
     ap.add_argument("--mode", default="net", choices=["net", "convstack"])
     ap.add_argument("--no-overlap", action="store_true", help="net mode: keep every layer on one stream (no branch concurrency)")
@@ -93,7 +101,7 @@ def cpu_baseline(net, procs):
     import oracle
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(ncpu))
-    procs = procs or min(ncpu, 64)
+    procs = procs or ncpu
     kind = "reference" if oracle.have_ref() else "port"
     reps = 2 if kind == "reference" else 1
     ctx = mp.get_context("spawn")
@@ -118,31 +126,6 @@ def cpu_baseline(net, procs):
                       f"cores (reference AVX Winograd is single-thread only), warmup 1 + {reps} timed reps per layer, "
                       f"{wall:.1f}s wall",
             "single_core_images_per_s": round(1.0 / single, 3), "cpu_model": model, "host_cores": ncpu}
-
-
-def pmc_traffic(net, bound):
-    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/<round>_<net>/traffic.json, written by tools/profile.sh + tools/summarize_prof.py: separate --pmc
-    passes for FETCH_SIZE and WRITE_SIZE, read side doubled per MI355X_MICROARCH.md's gfx950 note).  null if no profile."""
-    tag = {"vgg16": "vgg16", "resnet50": "resnet50", "mobilenet_v1": "mobilenet"}.get(net, net)
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, d, "traffic.json")
-        if d.endswith("_" + tag) and os.path.exists(f):
-            best = f  # the latest round wins
-    if not best:
-        return {"traffic": None}
-    want = "WinoGemmPolicy" if bound == "mfma" else "depthwise"
-    tot, n = 0.0, 0
-    for k, v in json.load(open(best)).items():
-        if want in k:
-            tot += v["hbm_bytes_per_launch"] * v["launches_profiled"]
-            n += v["launches_profiled"]
-    if not n:
-        return {"traffic": None}
-    return {"traffic": round(tot / n), "traffic_unit": "bytes per launch (avg over the kernel's launches)",
-            "traffic_source": os.path.relpath(best, ROOT)}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -186,9 +169,9 @@ def net_cpu_baseline(net_name, model, procs):
     except OSError:
         pass
     per_proc = 6 * len(b) + (1 << 30)  # raw blobs + packed copies + transient Mat + python
-    procs = procs or max(1, min(ncpu, 64, int(avail * 0.5 // per_proc) if avail else 8))
+    procs = procs or max(1, min(ncpu, int(avail * 0.6 // per_proc) if avail else 8))
     kind = "reference" if netcheck.have_ref_net() else "port"
-    reps = 2
+    reps = 1
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with tempfile.TemporaryDirectory() as d:
@@ -217,122 +200,179 @@ def net_cpu_baseline(net_name, model, procs):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def winograd_and_depthwise_work(net_name, batch, tuned=False):
-    """Algorithmic work of the roofline kernels per step, from the conv shape list:
-    tile-GEMM FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N over the layers SelectAlgo routes to WINOGRADF63, depthwise bytes
-    4*(C*Hin*Win + C*Ho*Wo)*N + 40*C over the DEPTHWISE layers, direct-conv FLOPs (ConvParam::GetFLOPS) over all."""
-    from feathercnn_amd import ConvBooster, booster, nets, WINOGRADF63, DEPTHWISE
-    gemm_flops = dw_bytes = direct = 0.0
-    n_conv = 0
-    for layer in nets.NETS[net_name]():
-        prm = nets.layer_param(layer, batch)
-        cb = ConvBooster()
-        cb.SelectAlgo(prm, tuned)
-        direct += prm.GetFLOPS() * batch
-        n_conv += 1
-        if cb.algo == WINOGRADF63:
-            pl = booster.winograd_plan(prm)
-            gemm_flops += 2.0 * 64 * prm.output_channels * prm.input_channels * pl.tiles_per_image * batch
-        elif cb.algo == DEPTHWISE:
-            dw_bytes += 4.0 * (prm.input_channels * prm.input_h * prm.input_w + prm.output_channels * prm.output_h * prm.output_w) * batch \
-                + 40.0 * prm.input_channels
-    return gemm_flops, dw_bytes, direct, n_conv
+def roofline_mfma(kernel, flops, ms, note):
+    ach = flops / ms / 1e9
+    return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None, "work_per_step": flops, "ms_per_step": round(ms, 4), "note": note}
 
 
-def make_roofline(net_name, gemm_flops, gemm_ms, dw_bytes, dw_ms):
-    roofline = None
-    if net_name == "mobilenet_v1" and dw_ms > 0:
-        ach = dw_bytes / dw_ms / 1e6
-        roofline = {"kernel": "depthwise3x3_direct_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                    "note": "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C summed over the 13 depthwise launches of a step / "
-                            "sum of their HIP-event durations on the launch stream, taken in an eager pass of the same step right after the "
-                            "timed region"}
-    elif gemm_ms > 0:
-        ach = gemm_flops / gemm_ms / 1e9
-        roofline = {"kernel": "Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
-                    "note": "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
-                            "sum of their tile-GEMM HIP-event durations on the launch stream, taken in an eager pass of the same step right "
-                            "after the timed region (the timed steps replay a hipGraph, which cannot carry per-kernel events)"}
-    if roofline is not None:
-        roofline.update(pmc_traffic(net_name, roofline["bound"]))
-    return roofline
+def roofline_hbm(kernel, nbytes, ms, note):
+    ach = nbytes / ms / 1e6
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "work_per_step": nbytes, "ms_per_step": round(ms, 4), "note": note}
+
+
+TRAFFIC_NOTE = ("traffic (HBM bytes from rocprofv3 PMC passes) cannot be collected inside this process; the per-round counters of "
+                "this same command are committed under profiles/ (tools/profile.sh)")
+
+
+def attribute(net, reps):
+    """After the timed region: eager forwards with HIP events on the launch stream around every kernel (stage timers of the C-ABI)
+    and around every layer, joined with each convolution's geometry as it runs -> per-kernel algorithmic work / measured time.
+    (The timed steps replay a hipGraph, which cannot carry per-kernel events.)"""
+    from feathercnn_amd import ALGO_NAMES, DEPTHWISE, IM2COL, WINOGRADF63, booster
+    algo_id = {v: k for k, v in ALGO_NAMES.items()}
+    net.set_graph(False)
+    booster.stage_timing(True)
+    booster.stage_timing_collect()
+    for _ in range(reps):
+        net.Forward()
+    st = booster.stage_timing_collect()
+    booster.stage_timing(False)
+    stage = {k: v[0] / reps for k, v in st.items() if v[1]}
+    per_layer = None
+    for _ in range(reps):
+        timed = net.forward_timed()
+        ms = [t[3] for t in timed]
+        per_layer = ms if per_layer is None else [x + y for x, y in zip(per_layer, ms)]
+    per_layer = [x / reps for x in per_layer]
+    info = net.layers()
+    convs = net.conv_params()
+    by_type, table = {}, []
+    gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = direct = 0.0
+    pw_rows = []
+    for i, ((typ, nm, algo), ms) in enumerate(zip(info, per_layer)):
+        key = typ + ("/" + algo if algo else "")
+        by_type[key] = by_type.get(key, 0.0) + ms
+        row = {"layer": nm, "type": typ, "algo": algo, "ms": round(ms, 4)}
+        if i in convs:
+            p, n = convs[i]
+            fl = 2.0 * p.output_channels * (p.input_channels // max(p.group, 1)) * p.output_h * p.output_w * p.kernel_h * p.kernel_w * n
+            direct += fl
+            row.update({"C": p.input_channels, "K": p.output_channels, "H": p.input_h, "k": p.kernel_h, "s": p.stride_h, "batch": n,
+                        "direct_tflops": round(fl / max(ms, 1e-9) / 1e9, 2)})
+            a_id = algo_id.get(algo)
+            if a_id == WINOGRADF63:
+                tiles = ((p.output_h + 5) // 6) * ((p.output_w + 5) // 6)
+                gemm_flops += 2.0 * 64 * p.output_channels * p.input_channels * tiles * n
+                k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
+            elif a_id == DEPTHWISE:
+                dw_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + p.output_channels * p.output_h * p.output_w) * n + 40.0 * p.input_channels
+                dw_ms += ms
+            elif a_id == IM2COL and p.kernel_h == 1 and p.kernel_w == 1:
+                pw_flops += fl
+                pw_ms += ms
+                row["mfma_frac"] = round(fl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)
+                pw_rows.append(row["mfma_frac"])
+        table.append(row)
+    roofs = []
+    if gemm_flops and stage.get("wino_gemm"):
+        roofs.append(roofline_mfma("Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", gemm_flops,
+                                   stage["wino_gemm"], "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
+                                   "sum of their tile-GEMM HIP-event durations on the launch stream"))
+    if pw_flops and pw_ms:
+        r = roofline_mfma("1x1 implicit GEMM: gemm_mfma_kernel<ConvGemmPolicy<1|2>> (+ split-K reduce)", pw_flops, pw_ms,
+                          "ConvParam::GetFLOPS 2*K*C*Ho*Wo*N summed over the 1x1 convolution layers of a step / sum of their per-layer "
+                          "HIP-event durations (bias, ReLU, folded BatchNorm and fused residual included)")
+        r["layers"] = len(pw_rows)
+        r["layer_frac_min"] = min(pw_rows)
+        r["layer_frac_mean"] = round(sum(pw_rows) / len(pw_rows), 4)
+        roofs.append(r)
+    if dw_bytes and dw_ms:
+        roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, dw_ms, "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C summed "
+                                  "over the depthwise layers of a step / sum of their HIP-event durations"))
+    if k2_bytes and stage.get("wino_input"):
+        roofs.append(roofline_hbm("wino_input_transform_kernel", k2_bytes, stage["wino_input"], "4*(C*H*W + 64*C*T)*N summed over the Winograd "
+                                  "layers / sum of the input-transform HIP-event durations"))
+    return {"stage_ms_per_step": {k: round(v, 4) for k, v in stage.items()},
+            "layer_type_ms_per_step": {k: round(v, 4) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1])},
+            "rooflines": roofs, "conv_direct_flops_per_step": direct, "table": table}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def per_gpu_batch(a, env):
-    """Weak scaling: the configured per-GPU batch.  Strong scaling (--global-batch): this rank's shard of the total."""
-    if a.global_batch:
+def per_gpu_batch(net_name, a, env, global_batch=0, batch=0):
+    """Weak scaling: the configured per-GPU batch.  Strong scaling (global batch): this rank's shard of the total."""
+    if global_batch:
         from feathercnn_amd.shard import shard_range
-        lo, hi = shard_range(a.global_batch, env["rank"], env["world"])
+        lo, hi = shard_range(global_batch, env["rank"], env["world"])
         if hi - lo < 1:
-            raise SystemExit("bench: --global-batch smaller than the number of GPUs")
+            raise SystemExit("bench: the global batch is smaller than the number of GPUs")
         return hi - lo
-    return a.batch or DEFAULT_BATCH[a.net]
+    return batch or DEFAULT_BATCH[net_name]
 
 
-def setup_net(a, env):
-    """Whole-net mode.  -> (step, finalize)"""
+def timed_region(step, steps, warmup, env):
+    """The contract's timing: W untimed steps, then exactly K steps bracketed by barrier + synchronize, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    world, dev = env["world"], env["dev"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail=True):
+    """One benchmark network through the feather::Net runtime: build (rank 0) + one RCCL broadcast of the .bin, timed region,
+    per-kernel attribution.  -> result dict (rank 0 carries the detail)."""
     import numpy as np
     import torch
 
-    from feathercnn_amd import booster, model_zoo
+    from feathercnn_amd import model_zoo
     from feathercnn_amd.net import Net
-    dev, rank, world = env["dev"], env["rank"], env["world"]
-    batch = per_gpu_batch(a, env)
-    build = model_zoo.MODELS[a.net]
-    # ---- model: generated on rank 0, the .bin broadcast once over RCCL (the only collective of this path) ------------
     from feathercnn_amd.shard import broadcast_model
-    model, t_bcast, bcast_bytes = broadcast_model(build, dev, src=0)
+    dev, rank, world = env["dev"], env["rank"], env["world"]
+    nb = per_gpu_batch(net_name, a, env, global_batch, batch)
+    model, t_bcast, bcast_bytes = broadcast_model(model_zoo.MODELS[net_name], dev, src=0)
     p, b, in_name, out_name = model
     net = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection, concurrency=not a.no_overlap)
     net.LoadParam(p)
     net.LoadWeights(b)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
-    x = torch.rand((batch, 3, 224, 224), device=dev, generator=gen) * 2 - 1
+    x = torch.rand((nb, 3, 224, 224), device=dev, generator=gen) * 2 - 1
     net.FeedInput(in_name, x)
     net.Forward()  # Reshape + Init (weight upload and transforms) + first forward; graph capture happens here
     torch.cuda.synchronize()
     prob = net.Extract(out_name)
     if not np.isfinite(prob).all() or abs(float(prob[0].sum()) - 1.0) > 1e-3:
-        raise SystemExit("bench: the net's output is not a probability vector")
-
-    def finalize(ms_per_step):
-        res = {"metric": "images/sec fp32 forward @224x224", "launch": "hipGraph replay per step" if not a.no_graph else "eager launches"}
-        gemm_flops, dw_bytes, direct, n_conv = winograd_and_depthwise_work(a.net, batch, not a.reference_selection)
-        layers = net.layers()
-        res["workload"] = (f"{a.net} whole net ({len(netcheck_layers(p))} layers in the model file, {len(layers)} after fusion level "
-                           f"{a.fusion}, {n_conv} convolutions), batch {batch} per GPU, 224x224x3, fp32, synthetic ncnn .param/.bin")
-        if rank != 0:
-            return res
-        reps = max(3, min(a.steps, 10))
-        net.set_graph(False)
-        booster.stage_timing(True)
-        booster.stage_timing_collect()
-        for _ in range(reps):
-            net.Forward()
-        st = booster.stage_timing_collect()
-        booster.stage_timing(False)
-        stage = {k: v[0] / reps for k, v in st.items() if v[1]}
-        timed = net.forward_timed()
-        by_type = {}
-        for typ, nm, algo, ms in timed:
-            key = typ + ("/" + algo if algo else "")
-            by_type[key] = by_type.get(key, 0.0) + ms
-        res["stage_ms_per_step"] = {k: round(v, 4) for k, v in stage.items()}
-        res["layer_type_ms_per_step"] = {k: round(v, 4) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1])}
-        res["roofline"] = make_roofline(a.net, gemm_flops, stage.get("wino_gemm", 0.0), dw_bytes, stage.get("depthwise", 0.0))
-        res["conv_gflops_per_s_direct"] = round(direct * world / (ms_per_step * 1e6), 1)
+        raise SystemExit(f"bench: {net_name}: the net's output is not a probability vector")
+    dt = timed_region(net.Forward, steps, warmup, env)
+    total_images = global_batch if global_batch else world * nb
+    res = {"net": net_name, "images_per_s": round(total_images * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "warmup": warmup, "per_gpu_batch": nb, "global_batch": total_images, "scaling": "strong" if global_batch else "weak"}
+    if rank == 0 and detail:
+        att = attribute(net, max(3, min(steps, 5)))
+        n_model_layers = len(netcheck_layers(p))
+        res["workload"] = (f"{net_name} whole net ({n_model_layers} layers in the model file, {len(net.layers())} after fusion level {a.fusion}), "
+                           f"batch {nb} per GPU, 224x224x3, fp32, synthetic ncnn .param/.bin")
+        res["conv_tflops_direct"] = round(att.pop("conv_direct_flops_per_step") * world / (dt / steps) / 1e12, 2)
+        res.update(att)
         res["device_memory"] = net.memory()
-        res["table"] = [{"layer": nm, "type": typ, "algo": algo, "ms": round(ms, 4)} for typ, nm, algo, ms in timed]
         if world > 1:
             res["weight_broadcast"] = {"ms": round(t_bcast * 1e3, 3), "bytes": bcast_bytes, "collective": "1 flat RCCL broadcast of the .bin from rank 0"}
-        res["cpu_baseline_fn"] = lambda: net_cpu_baseline(a.net, model, a.cpu_procs)
-        return res
-
-    return net.Forward, finalize, batch
+    net.close()
+    del net, x
+    torch.cuda.empty_cache()
+    return res, model
 
 
 def netcheck_layers(param_text):
@@ -347,7 +387,7 @@ def setup_convstack(a, env):
     from feathercnn_amd import WINOGRADF63, DEPTHWISE, IM2COL, ALGO_NAMES
     from feathercnn_amd.shard import broadcast_weights
     dev, rank, world = env["dev"], env["rank"], env["world"]
-    batch = per_gpu_batch(a, env)
+    batch = per_gpu_batch(a.net, a, env, a.global_batch, a.batch)
     layers = nets.NETS[a.net]()
 
     # ---- weights: generated on rank 0, broadcast once over RCCL (the only collective of this path) -------------------
@@ -445,13 +485,18 @@ def setup_convstack(a, env):
             table.append(row)
         booster.stage_timing(False)
         res["stage_ms_per_step"] = {k: round(v, 4) for k, v in stage_tot.items()}
-        res["roofline"] = make_roofline(a.net, gemm_flops, gemm_ms, dw_bytes, dw_ms)
+        roofs = []
+        if gemm_flops and gemm_ms:
+            roofs.append(roofline_mfma("Winograd tile GEMM", gemm_flops, gemm_ms, "2*64*K*C*T*N over the Winograd layers / their tile-GEMM event durations"))
+        if dw_bytes and dw_ms:
+            roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, dw_ms, "4*(C*Hin*Win + C*Ho*Wo)*N + 40*C over the depthwise layers / their event durations"))
+        res["rooflines"] = roofs
+        res["roofline"] = (roofs[1] if a.net == "mobilenet_v1" and len(roofs) > 1 else roofs[0]) if roofs else None
         res["conv_gflops_per_s_direct"] = round(flops_direct_total * world / (ms_per_step * 1e6), 1)
         res["conv_direct_frac_of_mfma_peak"] = round(flops_direct_total / (ms_per_step * 1e6) / 1e3 / PEAK_MFMA_F32_TFLOPS, 4)
         res["table"] = table
         if world > 1:
             res["weight_broadcast"] = {"ms": round(t_bcast * 1e3, 3), "bytes": bcast_bytes, "collective": "1 flat RCCL broadcast from rank 0"}
-        res["cpu_baseline_fn"] = lambda: cpu_baseline(a.net, a.cpu_procs)
         return res
 
     return step, finalize, batch
@@ -482,63 +527,87 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    n_gpus = world
     env = {"dev": dev, "rank": rank, "world": world}
-    step, finalize, batch = (setup_net if a.mode == "net" else setup_convstack)(a, env)
+    explicit = a.net is not None
+    head_net = a.net or "vgg16"
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / a.steps * 1e3
-    total_images = a.global_batch if a.global_batch else n_gpus * batch
-    value = total_images * a.steps / dt
-
-    # ---- per-stage / per-layer HIP-event timing (separate pass, after the timed region) -------------------------------
-    extra = finalize(ms_per_step)
+    if a.mode == "convstack":
+        a.net = head_net
+        step, finalize, batch = setup_convstack(a, env)
+        dt = timed_region(step, a.steps, a.warmup, env)
+        head = finalize(dt / a.steps * 1e3)
+        total = a.global_batch if a.global_batch else world * batch
+        head.update({"net": head_net, "images_per_s": round(total * a.steps / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 4),
+                     "per_gpu_batch": batch, "global_batch": total, "scaling": "strong" if a.global_batch else "weak"})
+        model, extras = None, {}
+    else:
+        # ---- headline: BASELINE.json configs[1] (VGG-16, 32 images per GPU) unless --net says otherwise; weak scaling at N > 1
+        head, model = measure_net(head_net, a, env, a.steps, a.warmup, a.global_batch, a.batch)
+        extras = {}
+        if not explicit and not a.headline_only:
+            # ---- the other nets BASELINE.json's metric names, same process, same timing procedure
+            if world == 1:
+                for name in ("resnet50", "mobilenet_v1"):
+                    extras[name], _ = measure_net(name, a, env, a.steps, a.warmup)
+                # the one-GPU point of configs[4]'s strong-scaling curve (ResNet-50, 512 images in total)
+                extras["resnet50_global512"], _ = measure_net("resnet50", a, env, max(a.steps // 5, 5), max(a.warmup // 2, 1), global_batch=512,
+                                                              detail=False)
+            else:
+                # configs[4]: ResNet-50, 512 images in total sharded over the ranks (strong), plus its weak point (64 per GPU)
+                extras["resnet50_global512"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, global_batch=512)
+                extras["resnet50"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, detail=False)
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        table = extra.pop("table", [])
-        cpu_fn = extra.pop("cpu_baseline_fn", None)
         res = {
-            "metric": extra.pop("metric"), "value": round(value, 2), "unit": "images/s",
-            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": extra.pop("workload"), "net": a.net, "mode": a.mode, "per_gpu_batch": batch, "global_batch": total_images,
-                       "parallelism": f"batch-shard x{n_gpus}", "launch": extra.pop("launch"),
+            "metric": "images/sec fp32 forward @224x224" + (" (conv stack)" if a.mode == "convstack" else ""),
+            "value": head["images_per_s"], "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": head.get("workload", ""), "net": head_net, "mode": a.mode, "per_gpu_batch": head["per_gpu_batch"],
+                       "global_batch": head["global_batch"], "parallelism": f"batch-shard x{world}",
+                       "launch": "eager launches" if a.no_graph else "hipGraph replay per step",
                        "conv_routing": "reference SelectAlgo rule" if a.reference_selection else "fhip_conv_select_algo_tuned (Winograd also on 4..8-pixel 3x3 layers)",
                        "streams": "one" if (a.no_overlap or a.mode != "net") else "main + one side stream for arena-free branch convolutions"},
         }
-        roofline = extra.pop("roofline", None)
-        res.update(extra)
-        res["roofline"] = roofline
-        if not a.no_cpu_baseline and n_gpus == 1 and cpu_fn is not None:
+        table = head.pop("table", [])
+        cpu_fn = head.pop("cpu_baseline_fn", None)
+        for k in ("stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "conv_gflops_per_s_direct", "device_memory", "weight_broadcast"):
+            if k in head:
+                res[k] = head[k]
+        roofs = head.get("rooflines", [])
+        # the dominant kernel of the headline net: tile GEMM (MFMA) for VGG / ResNet, depthwise (HBM) for MobileNet
+        dom = None
+        for r in roofs:
+            if head_net == "mobilenet_v1" and r["kernel"].startswith("depthwise"):
+                dom = r
+        res["roofline"] = dom or (roofs[0] if roofs else head.get("roofline"))
+        res["rooflines"] = {head_net: roofs}
+        res["traffic_note"] = TRAFFIC_NOTE
+        nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling")}}
+        tables = {head_net: table}
+        for name, e in extras.items():
+            nets_out[name] = {k: e[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "steps", "warmup") if k in e}
+            for k in ("workload", "stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "device_memory"):
+                if k in e:
+                    nets_out[name][k] = e[k]
+            if "rooflines" in e:
+                res["rooflines"][name] = e["rooflines"]
+            tables[name] = e.get("table", [])
+        res["nets"] = nets_out
+        if not a.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_fn()
+                if a.mode == "convstack":
+                    res["cpu_baseline"] = cpu_baseline(head_net, a.cpu_procs)
+                else:
+                    res["cpu_baseline"] = net_cpu_baseline(head_net, model, a.cpu_procs)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
         if a.layers_out:
             os.makedirs(os.path.dirname(os.path.abspath(a.layers_out)), exist_ok=True)
             with open(a.layers_out, "w") as f:
-                json.dump({"net": a.net, "mode": a.mode, "batch": batch, "layers": table}, f, indent=1)
+                json.dump({"mode": a.mode, "tables": tables}, f, indent=1)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

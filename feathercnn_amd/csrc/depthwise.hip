@@ -16,6 +16,8 @@
 //     global-kernel special case).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace fhip
@@ -34,6 +36,8 @@ struct DwParams
     int has_bias, relu;
 };
 
+constexpr int kDwChunkFloats = 3136;   // plane data per block of the small-plane 3x3 kernel
+constexpr int kDwChunkMaxPlane = 1024; // planes up to 32 x 32 go there (measured against the direct kernel: tools/dw_bench.hip)
 constexpr int kDwLdsFloats = 14336; // 56 KiB of plane data per block (+ weights) -> 2 blocks per CU (depthwise_lds_scalar_kernel)
 
 // Direct 3x3 form: no LDS, every lane produces a VX-wide x R-high output patch straight from global memory.
@@ -129,11 +133,11 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
             {
                 lft = __shfl_up(x[r][NV * VX], 1);
                 rgt = __shfl_down(x[r][1], 1);
-                // a neighbouring lane is a neighbour in the IMAGE only inside one row block: the first / last vector of a row
-                // (and the wave's edge lanes) load for real -- with pad_right != pad_left the last vector's right tap is a real
-                // pixel (OW * S < W), not padding
-                if (lane == 0 || xq == 0) lft = row[max(xb - 1, 0)];
-                if (lane == 63 || xq == xvecs - 1) rgt = row[min(xb + NV * VX, q.W - 1)];
+                // A neighbouring lane is a neighbour in the IMAGE only inside one row block.  The first vector of a row never uses its
+                // left tap (xb == 0: padding, pad_left == 1); the last vector's right tap is padding too when OW * S == W, but a REAL
+                // pixel when pad_right < pad_left (OW * S < W) -- then the next lane belongs to another row and the tap is loaded.
+                if (lane == 0) lft = row[max(xb - 1, 0)];
+                if (lane == 63 || (xq == xvecs - 1 && xb + NV * VX < q.W)) rgt = row[min(xb + NV * VX, q.W - 1)];
             }
             else
             {
@@ -186,6 +190,101 @@ __global__ __launch_bounds__(256) void depthwise3x3_direct_kernel(const DwParams
                 for (int e = 0; e < VX; ++e) o[e] = apply_act(acc[e] + b, q.relu);
                 *reinterpret_cast<vec_t*>(op + (size_t)j * q.OW) = DwVec<VX>::pack(o);
             }
+        }
+    }
+}
+
+// 3x3 on SMALL planes (28x28 and below), stride 1 / 2, any pads.  The direct form above maps a lane to a VX x R patch: with 7 (28 px)
+// or 3 (14 px, 8-byte vectors) lanes per image row its 16-byte loads touch 10-20 partially used cache lines per instruction and it
+// ran at 34-53 % of the HBM peak there.  Here a block stages a small chunk of WHOLE planes -- consecutive planes are one contiguous
+// run of memory, so the copy is fully coalesced 16-byte loads whatever W is -- computes every output from LDS and writes four
+// consecutive outputs per lane as one 16-byte store (the output planes of a chunk are contiguous too).  The chunk is ~12 KB, not
+// the 56 KB of the whole-plane staging measured in round 1 (24 %): ten blocks share a CU, so the load, compute and store phases
+// of different blocks overlap.
+template <int S>
+__global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams q, int chunk_planes, int tile_floats)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const tile = smem;             // [chunk_planes][H][W]
+    float* const wl = smem + tile_floats; // [chunk_planes][12]: 9 taps, bias, 2 unused
+    const int HW = q.H * q.W, OHW = q.OH * q.OW;
+    const int tid = threadIdx.x;
+    const int plane0 = blockIdx.x * chunk_planes;
+    const int np = min(chunk_planes, q.planes - plane0);
+    {
+        // plane0 * HW is a multiple of 4 floats (the host picks chunk_planes % 4 == 0 unless HW % 4 == 0)
+        const float* srcf = q.in + (size_t)plane0 * HW;
+        const float4* src = reinterpret_cast<const float4*>(srcf);
+        float4* dst = reinterpret_cast<float4*>(tile);
+        const int nf = np * HW, n4 = nf >> 2;
+        float4 v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[b] = src[min(tid + b * 256, max(n4 - 1, 0))]; // every load in flight before the first LDS write
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (tid + b * 256 < n4) dst[tid + b * 256] = v[b];
+        for (int i = tid + 1024; i < n4; i += 256) dst[i] = src[i];
+        for (int i = (n4 << 2) + tid; i < nf; i += 256) tile[i] = srcf[i];
+        for (int i = tid; i < np * 12; i += 256)
+        {
+            const int pl = i / 12, e = i - pl * 12;
+            const int c = (plane0 + pl) % q.C;
+            wl[i] = e < 9 ? q.w[c * 9 + e] : ((e == 9 && q.has_bias) ? q.bias[c] : 0.f);
+        }
+    }
+    __syncthreads();
+    const int nout = np * OHW;
+    float* const obase = q.out + (size_t)plane0 * OHW;
+    const bool vec = (OHW & 3) == 0; // then 4 consecutive outputs share a plane and the store is 16-byte aligned
+    for (int o0 = tid * 4; o0 < nout; o0 += 1024)
+    {
+        float res[4];
+        int pl = o0 / OHW;
+        int r = o0 - pl * OHW;
+        int oy = r / q.OW, ox = r - oy * q.OW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            float acc = 0.f;
+            if (o0 + e < nout)
+            {
+                const float* ip = tile + pl * HW;
+                const float* wp = wl + pl * 12;
+                const int iy0 = oy * S - q.PT, ix0 = ox * S - q.PL;
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                {
+                    const int iy = iy0 + m;
+                    if ((unsigned)iy >= (unsigned)q.H) continue;
+                    const float* row = ip + iy * q.W;
+#pragma unroll
+                    for (int n = 0; n < 3; ++n)
+                    {
+                        const int ix = ix0 + n;
+                        const float xv = row[min(max(ix, 0), q.W - 1)];
+                        acc += (((unsigned)ix < (unsigned)q.W) ? xv : 0.f) * wp[m * 3 + n];
+                    }
+                }
+                acc = apply_act(acc + wp[9], q.relu);
+            }
+            res[e] = acc;
+            if (++ox == q.OW)
+            {
+                ox = 0;
+                if (++oy == q.OH)
+                {
+                    oy = 0;
+                    ++pl;
+                }
+            }
+        }
+        if (vec)
+            *reinterpret_cast<float4*>(obase + o0) = make_float4(res[0], res[1], res[2], res[3]);
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (o0 + e < nout) obase[o0 + e] = res[e];
         }
     }
 }
@@ -351,7 +450,25 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     const int HW = q.H * q.W;
     StageTimer tm(FHIP_STAGE_DEPTHWISE, s);
     const bool k3 = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1;
-    if (k3)
+    // small planes (28 x 28 and below at MobileNet's shapes): the chunk-of-planes kernel; larger ones: the direct kernel
+    const bool small_plane = k3 && HW <= kDwChunkMaxPlane && q.OH * q.OW >= 1;
+    if (small_plane)
+    {
+        // ~3136 floats (12.25 KB) of planes per block: 4 x 28^2, 16 x 14^2, 64 x 7^2; a multiple of 4 planes keeps every chunk
+        // 16-byte aligned whatever HW is
+        int cp = std::max(1, kDwChunkFloats / HW);
+        if (HW % 4) cp = std::max(4, cp / 4 * 4);
+        cp = (int)std::min<long long>(cp, planes);
+        const int tile_floats = round_up(cp * HW, 4);
+        const size_t lds = (size_t)(tile_floats + cp * 12) * sizeof(float);
+        const long long chunks = (planes + cp - 1) / cp;
+        if (chunks > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N*C too large");
+        if (q.SH == 1)
+            hipLaunchKernelGGL(depthwise3x3_chunk_kernel<1>, dim3((unsigned)chunks), dim3(256), lds, s, q, cp, tile_floats);
+        else
+            hipLaunchKernelGGL(depthwise3x3_chunk_kernel<2>, dim3((unsigned)chunks), dim3(256), lds, s, q, cp, tile_floats);
+    }
+    else if (k3)
     {
         const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
         // output rows per lane: 4 at stride 1, 2 at stride 2 (measured against 1, 2 and 7: DESIGN.md 3.3)

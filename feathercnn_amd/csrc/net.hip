@@ -339,6 +339,7 @@ struct Layer
     virtual size_t weight_bytes() const { return 0; }
     virtual size_t arena_bytes() const { return 0; }
     virtual int algo() const { return -1; }
+    virtual const fhip_conv_param* conv_param() const { return nullptr; }
 };
 
 struct Net
@@ -547,6 +548,7 @@ struct ConvLayer : Layer
     }
     size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes; }
     size_t arena_bytes() const override { return buffer_bytes; }
+    const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
 };
 
@@ -1441,6 +1443,18 @@ int fhip_net_layer_info(fhip_net* n, int index, char* type, char* name, int len,
     if (type && len > 0) snprintf(type, len, "%s", l->type.c_str());
     if (name && len > 0) snprintf(name, len, "%s", l->name.c_str());
     if (algo) *algo = l->algo();
+    return FHIP_OK;
+}
+
+int fhip_net_layer_conv_param(fhip_net* n, int index, fhip_conv_param* param, int* batch)
+{
+    NET_GUARD(n);
+    if (index < 0 || index >= (int)n->impl.layers.size() || !param) return fail(FHIP_E_BADARG, "layer index out of range");
+    Layer* l = n->impl.layers[index].get();
+    const fhip_conv_param* cp = l->conv_param();
+    if (!cp) return fail(FHIP_E_BADARG, "not a convolution layer");
+    *param = *cp;
+    if (batch) *batch = l->bottoms.empty() ? 0 : l->bottoms[0]->n;
     return FHIP_OK;
 }
 

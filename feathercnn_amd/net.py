@@ -114,6 +114,15 @@ class Net:
             out.append((t.value.decode(), nm.value.decode(), ALGO_NAMES.get(algo.value)))
         return out
 
+    def conv_params(self):
+        """{layer index: (fhip_conv_param, batch)} for the convolution layers as they run (after Reshape)."""
+        out = {}
+        for i in range(self._lib.fhip_net_layer_count(self._h)):
+            p, b = _lib.fhip_conv_param(), ctypes.c_int()
+            if self._lib.fhip_net_layer_conv_param(self._h, i, ctypes.byref(p), ctypes.byref(b)) == 0:
+                out[i] = (p, b.value)
+        return out
+
     def forward_timed(self):
         """One eager forward with HIP events around every layer: [(type, name, algo, ms)]."""
         n = self._lib.fhip_net_layer_count(self._h)

@@ -118,6 +118,10 @@ FHIP_API int fhip_net_layer_count(fhip_net* net);
 /* type / name are copied (truncated) into caller buffers of `len` bytes; algo = fhip_conv_algo for
  * convolutions after the first Forward, else -1. */
 FHIP_API int fhip_net_layer_info(fhip_net* net, int index, char* type, char* name, int len, int* algo);
+/* Geometry of a Convolution / ConvolutionDepthWise layer as it runs (after Reshape: output dims assigned, BatchNorm folded, ...) and
+ * the batch of its input blob; FHIP_E_BADARG for any other layer type.  (bench.py prices each layer's kernel against its roofline
+ * with ConvParam::GetFLOPS, booster.h:145-148.) */
+FHIP_API int fhip_net_layer_conv_param(fhip_net* net, int index, fhip_conv_param* param, int* batch);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

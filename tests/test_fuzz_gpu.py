@@ -107,3 +107,31 @@ def test_random_geometry(idx, cuda, port):
             assert rc == 0
             torch.cuda.synchronize()
             assert torch.equal(out, expect), (g, batch, "fused residual")
+
+
+# Asymmetric pads are legal in the C-ABI (ConvParam carries the four pads separately, booster.h:68-71) although feather::ConvLayer
+# only ever sets symmetric ones.  ADVICE r01: with pad_right < pad_left the last output column's right tap is a real pixel, not
+# padding -- the depthwise kernel used to take it from a lane that belongs to another row.
+ASYM = [Geom(c, c, h, w, 3, 3, s, s, pl, pr, pt, pb, c, 1, 1)
+        for (c, h, w, s, pl, pr, pt, pb) in [(8, 12, 16, 1, 1, 0, 1, 1), (8, 12, 17, 1, 1, 0, 1, 0), (6, 9, 14, 1, 1, 2, 0, 1), (5, 20, 32, 1, 1, 0, 1, 1),
+                                             (4, 16, 16, 2, 1, 0, 1, 0), (7, 15, 18, 2, 1, 2, 1, 1), (3, 28, 28, 1, 1, 0, 0, 0), (16, 14, 14, 2, 1, 0, 0, 1)]] + \
+       [Geom(8, 12, 13, 19, 3, 3, 1, 1, 1, 0, 1, 0, 1, 1, 1), Geom(8, 8, 14, 14, 3, 3, 1, 1, 2, 0, 0, 1, 1, 1, 0), Geom(12, 8, 10, 11, 5, 3, 2, 1, 0, 2, 3, 1, 1, 1, 1),
+        Geom(16, 16, 9, 9, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("g", ASYM, ids=lambda g: f"c{g.ic}g{g.group}_{g.ih}x{g.iw}_k{g.kh}x{g.kw}s{g.sh}_p{g.pl}{g.pr}{g.pt}{g.pb}")
+def test_asymmetric_pads(g, cuda, port):
+    import torch
+    from feathercnn_amd import ConvLayer
+    batch = 3
+    x, w, b = synth(g, batch, seed=99)
+    want = port.forward(g, x, w, b)
+    f64 = port.direct_f64(g, x, w, b if g.bias else None)
+    if g.act:
+        f64 = np.maximum(f64, 0)
+    assert nerr(want, f64) <= TOL, "the checker itself disagrees with fp64"
+    for tuned in (False, True):
+        lyr = ConvLayer(_param(g, batch), torch.from_numpy(w).to(cuda), torch.from_numpy(b).to(cuda) if g.bias else None, tuned=tuned)
+        y = lyr.Forward(torch.from_numpy(x).to(cuda))
+        torch.cuda.synchronize()
+        assert nerr(y.cpu().numpy(), want) <= TOL, (g, tuned, lyr.booster.algo)

@@ -131,3 +131,47 @@ def test_cpp_net_class_compiles_and_reads_models(tmp_path):
                     "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
     out = subprocess.run([exe, str(tmp_path / "m.param"), str(tmp_path / "m.bin")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "net api ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_reference_style_application_compiles_unchanged(tmp_path):
+    """A main() written against the reference's own public API -- #include <net.h>, feather::Net, FeedInput(const char*, ncnn::Mat&),
+    Extract(std::string, ncnn::Mat&) (reference src/net.h:44,50) -- compiles against include/ and links against the product library
+    without a source change; the minimal ncnn::Mat behaves like the reference's for the calls such programs make."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from feathercnn_amd import _lib
+    libdir = os.path.dirname(_lib.lib_path())
+    exe = str(tmp_path / "ref_main")
+    inc = os.path.join(root, "include")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I" + inc, "-I" + os.path.join(inc, "feather"), os.path.join(root, "tests", "cpp", "reference_style_main.cpp"),
+                    "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    mat_test = tmp_path / "mat_test.cpp"
+    mat_test.write_text(r"""
+#include <ncnn/mat.h>
+#include <stdio.h>
+int main()
+{
+    ncnn::Mat m(5, 3, 2);                       // w, h, c: plane = 15 floats = 60 B -> channel stride padded to 64 B = 16 floats
+    if (m.dims != 3 || m.w != 5 || m.h != 3 || m.c != 2 || m.cstep != 16 || m.elemsize != 4 || m.total() != 32 || m.empty()) return 1;
+    m.fill(2.f);
+    float* c1 = m.channel(1);
+    c1[0] = 7.f;
+    if (((float*)m.data)[16] != 7.f || m.channel(1).row(0)[0] != 7.f) return 2;
+    ncnn::Mat view = m;                         // shares
+    ncnn::Mat deep = m.clone();
+    c1[1] = 9.f;
+    if (((float*)view.data)[17] != 9.f || ((float*)deep.data)[17] != 2.f) return 3;
+    ncnn::Mat ext(4, 4, 3, (void*)c1);          // external data: 4*4*4 = 64 B planes, no padding
+    if (ext.cstep != 16 || ext.refcount != 0) return 4;
+    m.create(5, 3, 2);                          // same shape: keeps the allocation
+    if (((float*)m.data)[16] != 7.f) return 5;
+    m.create(8, 8, 1);
+    if (m.cstep != 64) return 6;
+    printf("mat ok\n");
+    return 0;
+}
+""")
+    exe2 = str(tmp_path / "mat_test")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I" + inc, str(mat_test), "-o", exe2], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe2], capture_output=True, text=True)
+    assert out.returncode == 0 and "mat ok" in out.stdout, out.stdout + out.stderr

@@ -260,6 +260,32 @@ def test_cpp_net_class_forward(cuda, tmp_path):
     assert nerr(y, g["tiny/blob/prob"]) <= TOL
 
 
+def test_reference_style_application_runs(cuda, tmp_path):
+    """tests/cpp/reference_style_main.cpp (the reference's own public API, unchanged source) end to end: FeedInput(ncnn::Mat) with a
+    padded channel stride (20 x 20 planes are 1600 B: no padding; 19 x 19 are 1444 B -> 1456), Extract(ncnn::Mat), against the checker."""
+    import subprocess
+    from feathercnn_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    libdir = os.path.dirname(_lib.lib_path())
+    exe = str(tmp_path / "ref_main")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-I" + inc, "-I" + os.path.join(inc, "feather"), os.path.join(root, "tests", "cpp", "reference_style_main.cpp"),
+                    "-o", exe, "-L" + libdir, "-lfeather_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    for size in (20, 19):
+        p, b, i, o = model_zoo.tiny_allsorts(size=size)
+        (tmp_path / "m.param").write_bytes(p)
+        (tmp_path / "m.bin").write_bytes(b)
+        x = np.random.default_rng(size).uniform(-1, 1, (1, 3, size, size)).astype(np.float32)
+        x.astype("<f4").tofile(str(tmp_path / "x.f32"))
+        for blob in ("prob", "cat"):
+            out = subprocess.run([exe, str(tmp_path / "m.param"), str(tmp_path / "m.bin"), str(tmp_path / "x.f32"), "3", str(size), str(size), blob,
+                                  str(tmp_path / "y.f32")], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0 and "reference-style main ok" in out.stdout, out.stdout + out.stderr
+            want = (netcheck.RefNet(p, b) if netcheck.have_ref_net() else netcheck.PortNet(p, b)).run(i, x, blob)
+            y = np.fromfile(str(tmp_path / "y.f32"), "<f4").reshape(want.shape)
+            assert nerr(y, want) <= TOL, (size, blob)
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 20, 20), (16, 64, 36, 28), (4, 8, 16, 44), (32, 32, 14, 14), (8, 8, 12, 10)])
 def test_conv_with_fused_maxpool_equals_conv_then_pool(cuda, shape):
     """fhip_conv_forward_maxpool2 (Winograd output transform writing the pooled tensor) == ConvLayer + PoolingLayer."""

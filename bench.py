@@ -238,6 +238,8 @@ def attribute(net, reps):
     per_layer = [x / reps for x in per_layer]
     info = net.layers()
     convs = net.conv_params()
+    fused_pw = net.fused_pointwise()
+    fz_flops = fz_bytes = fz_ms = 0.0
     by_type, table = {}, []
     gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = direct = 0.0
     pw_rows = []
@@ -252,7 +254,18 @@ def attribute(net, reps):
             row.update({"C": p.input_channels, "K": p.output_channels, "H": p.input_h, "k": p.kernel_h, "s": p.stride_h, "batch": n,
                         "direct_tflops": round(fl / max(ms, 1e-9) / 1e9, 2)})
             a_id = algo_id.get(algo)
-            if a_id == WINOGRADF63:
+            if i in fused_pw:
+                # a 3x3 depthwise layer and the 1x1 convolution behind it running as ONE kernel (fhip_conv_forward_dw_pw): the pair's
+                # compulsory bytes are its input and its output, its matrix work the pointwise GEMM
+                q = fused_pw[i]
+                pfl = 2.0 * q.output_channels * q.input_channels * q.output_h * q.output_w * n
+                direct += pfl
+                fz_flops += pfl
+                fz_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + q.output_channels * q.output_h * q.output_w) * n
+                fz_ms += ms
+                row.update({"fused_pointwise_K": q.output_channels, "pair_gbs": round(4.0 * (p.input_channels * p.input_h * p.input_w + q.output_channels *
+                            q.output_h * q.output_w) * n / max(ms, 1e-9) / 1e6, 1), "pair_mfma_frac": round(pfl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)})
+            elif a_id == WINOGRADF63:
                 tiles = ((p.output_h + 5) // 6) * ((p.output_w + 5) // 6)
                 gemm_flops += 2.0 * 64 * p.output_channels * p.input_channels * tiles * n
                 k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
@@ -281,6 +294,11 @@ def attribute(net, reps):
     if dw_bytes and dw_ms:
         roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, dw_ms, "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C summed "
                                   "over the depthwise layers of a step / sum of their HIP-event durations"))
+    if fz_ms:
+        roofs.append(roofline_hbm("fused depthwise 3x3 + 1x1: gemm_mfma_kernel<ConvGemmPolicy<3|4>>", fz_bytes, fz_ms, "input of the depthwise + output "
+                                  "of the pointwise layer (the depthwise output never exists) summed over the fused pairs / their HIP-event durations"))
+        roofs.append(roofline_mfma("fused depthwise 3x3 + 1x1 (the same launches, matrix side)", fz_flops, fz_ms, "2*K*C*Ho*Wo*N of the pointwise "
+                                   "halves / the same durations"))
     if k2_bytes and stage.get("wino_input"):
         roofs.append(roofline_hbm("wino_input_transform_kernel", k2_bytes, stage["wino_input"], "4*(C*H*W + 64*C*T)*N summed over the Winograd "
                                   "layers / sum of the input-transform HIP-event durations"))

@@ -63,6 +63,8 @@ SIGNATURES = {
     "fhip_affine": (_I, [_V, _V, _V, _V, _I, _I, _I, _I, _V]),
     "fhip_conv_can_fuse_residual": (_I, [_P, _I]),
     "fhip_conv_forward_residual": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V, _V]),
+    "fhip_conv_can_fuse_dw_pw": (_I, [_P, _P, _I]),
+    "fhip_conv_forward_dw_pw": (_I, [_P, _P, _I, _V, _V, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_maxpool2": (_I, [_P, _I]),
     "fhip_conv_forward_maxpool2": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V]),
     "fhip_pooling_output_dim": (_I, [_Q, _PI, _PI]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "fhip_net_layer_count": (_I, [_V]),
     "fhip_net_layer_info": (_I, [_V, _I, ctypes.c_char_p, ctypes.c_char_p, _I, _PI]),
     "fhip_net_layer_conv_param": (_I, [_V, _I, _P, _PI]),
+    "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P]),
     "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
     "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }

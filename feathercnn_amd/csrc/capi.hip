@@ -30,6 +30,9 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
                       hipStream_t s);
 int depthwise_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 size_t depthwise_packed_floats(const fhip_conv_param& p, size_t* w12_offset);
+bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch);
+int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch, float* out, const float* in, const float* dw_packed,
+                 const float* dw_bias, const float* pw_packed, const float* pw_bias, hipStream_t s);
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -262,6 +265,18 @@ int fhip_conv_can_fuse_residual(const fhip_conv_param* p, int algo) { return val
 int fhip_conv_can_fuse_maxpool2(const fhip_conv_param* p, int algo)
 {
     return valid_param(p) && algo == FHIP_WINOGRADF63 && winograd_can_pool(*p) ? 1 : 0;
+}
+
+int fhip_conv_can_fuse_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch)
+{
+    return valid_param(dw) && valid_param(pw) && dwpw_applicable(*dw, *pw, batch) ? 1 : 0;
+}
+
+int fhip_conv_forward_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch, float* output, const float* input,
+                            const float* dw_packed, const float* dw_bias, const float* pw_packed, const float* pw_bias, void* stream)
+{
+    if (!valid_param(dw) || !valid_param(pw) || !output || !input || !dw_packed || !pw_packed || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
+    return dwpw_forward(*dw, *pw, batch, output, input, dw_packed, dw_bias, pw_packed, pw_bias, (hipStream_t)stream);
 }
 
 int fhip_winograd_f63_transform_kernel(const fhip_conv_param* p, float* u, const float* kernel, void* stream)

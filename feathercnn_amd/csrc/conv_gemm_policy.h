@@ -4,6 +4,8 @@
 // residual epilogue of packed_sgemm_activation<bias,relu> (avx/sgemm.cpp:377-433).
 #pragma once
 
+#include <type_traits>
+
 #include "gemm_core.h"
 
 namespace fhip
@@ -37,15 +39,40 @@ struct ConvGemmParams
     // carried as a byte offset from `out` so the store path needs no second pointer table
     int has_residual;
     ptrdiff_t residual_delta;
+    // MODE 3 / 4 (depthwise 3x3 fused into the 1x1 convolution that consumes it): `in` is the DEPTHWISE layer's input [N][C][H][W],
+    // the B operand is act(dw3x3(in) + dw_bias) computed on the fly; OH/OW are the depthwise output = pointwise input / output dims
+    const float* dw_w12; // [C][12]: 9 taps + 3 unused (depthwise_init's 16-byte tap rows)
+    const float* dw_bias;
+    int dw_stride, dw_relu;
 };
+
+constexpr int kDwFusedMaxC = 256; // channels whose taps the fused route keeps in LDS (12 floats each)
 
 // MODE 0: generic gather (any kernel / stride / pad)
 // MODE 1: 1x1, pad 0, any stride (no tap decode, no bounds checks)
 // MODE 2: 1x1, stride 1, pad 0, OH*OW % 4 == 0 : the column matrix IS the input -> 16-byte loads
+// MODE 3 / 4: 1x1 stride 1 on the OUTPUT of a 3x3 depthwise convolution (MODE 3: depthwise stride 1, MODE 4: stride 2; pad_left =
+//         pad_top = 1, W % 4 == 0, OW % 4 == 0, C <= kDwFusedMaxC) that is never written: the B loader fetches the depthwise INPUT
+//         patch of its 4 output pixels -- per channel 3 rows x (4-byte, 16-byte, 4- or 16-byte) loads -- and `finish` does the 36
+//         FMAs at LDS-write time, a k-tile after the loads were issued.  MobileNet's first pairs are HBM bound: the pair's
+//         compulsory traffic drops from in + 2*mid + out to in + out.  (Taking the two halo columns from the neighbouring lanes with
+//         shuffles -- 6 loads instead of 9 -- was measured: faster on the 64-row tile, slower on the 128-row one: the route is bound
+//         by VALU issue next to the MFMAs, not by the address pipe.)
 template <int MODE>
 struct ConvGemmPolicy
 {
     using Params = ConvGemmParams;
+    static constexpr int EXTRA_LDS_FLOATS = MODE >= 3 ? kDwFusedMaxC * 12 : 0;
+    // MODE 3 / 4: the depthwise taps (9) + bias (slot 9) of every channel -> LDS, once per block
+    static __device__ void stage_extra(const Params& p, float* extra, int tid, int threads)
+    {
+        if (MODE < 3) return;
+        for (int i = tid; i < p.C * 12; i += threads)
+        {
+            const int c = i / 12, e = i - c * 12;
+            extra[i] = e == 9 ? (p.dw_bias ? p.dw_bias[c] : 0.f) : p.dw_w12[i];
+        }
+    }
 
     // bias of output row m for the prologue preload (split-K pieces store raw partial sums: no bias)
     static __device__ float bias_at(const Params& p, int m) { return (p.has_bias && p.split_k <= 1 && m < p.K) ? p.bias[m] : 0.f; }
@@ -67,17 +94,42 @@ struct ConvGemmPolicy
         }
     };
 
+    // MODE 3 / 4: the depthwise input patch of 4 output pixels of one channel, rows y-1, y, y+1 (x0 = input column of tap 1 of output 0)
+    struct DwRaw1 // stride 1: columns x0-1 .. x0+4
+    {
+        float l[3];
+        float4 c[3];
+        float r[3];
+    };
+    struct DwRaw2 // stride 2: columns x0-1 .. x0+7
+    {
+        float l[3];
+        float4 c[3];
+        float4 r[3];
+    };
     struct BLoad
     {
-        const float* ptr[MODE == 2 ? 1 : 4]; // &in[n][0][iy0][ix0] of each of the 4 columns (may point before the plane)
-        int iy0[MODE == 0 ? 4 : 1], ix0[MODE == 0 ? 4 : 1];
+        typedef typename std::conditional<MODE == 3, DwRaw1, typename std::conditional<MODE == 4, DwRaw2, float4>::type>::type Raw;
+        const float* ptr[(MODE >= 2) ? 1 : 4]; // &in[n][0][iy0][ix0] of each of the 4 columns (may point before the plane)
+        int iy0[MODE == 0 ? 4 : 1], ix0[MODE == 0 ? 4 : 1]; // MODE 3 / 4: [0] = first tap row / first centre column of the patch
         unsigned valid; // bit e: column n4+e < Ntot
         int koff;       // first reduction row of this K split
         __device__ BLoad(const Params& p, int split, int n4)
         {
             valid = 0;
             koff = k_first(p, split) * kConvKTile;
-            if (MODE == 2)
+            if (MODE >= 3)
+            {
+                // 4 consecutive columns are 4 consecutive pixels of one output row (OW % 4 == 0, n4 % 4 == 0)
+                const int cc = n4 < p.Ntot ? n4 : 0;
+                const int img = cc / p.OHW, rem = cc - img * p.OHW;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                valid = n4 < p.Ntot ? 0xfu : 0u;
+                iy0[0] = oy * p.dw_stride - 1; // input row of tap row 0 (pad_top = 1)
+                ix0[0] = ox * p.dw_stride;     // input column under output 0, tap column 1 (pad_left = 1)
+                ptr[0] = p.in + ((size_t)img * p.C) * p.HW;
+            }
+            else if (MODE == 2)
             {
                 // 4 consecutive columns stay inside one image (OHW % 4 == 0, n4 % 4 == 0)
                 const int img = n4 / p.OHW, rem = n4 - img * p.OHW;
@@ -106,7 +158,90 @@ struct ConvGemmPolicy
             }
         }
         // Unconditional loads from clamped addresses; `ok` says which of the 4 values are real (see gemm_core.h).
-        __device__ float4 load(const Params& p, int krow_in_split, unsigned& ok) const
+        // MODE 3 / 4: act(dw3x3 + bias) of the 4 pixels, taps accumulated in (m, n) order like depthwise3x3_direct_kernel
+        __device__ float4 finish(const Params& p, const Raw& raw, int krow_in_split, const float* extra) const
+        {
+            if constexpr (MODE < 3)
+                return raw;
+            else
+            {
+                const int c = min(krow_in_split + koff, p.C - 1);
+                const float* w = extra + c * 12;
+                constexpr int S = MODE == 3 ? 1 : 2;
+                float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                {
+                    if ((unsigned)(iy0[0] + m) >= (unsigned)p.H) continue; // padding row
+                    // t[j] = input column ix0 - 1 + j
+                    constexpr int NT = S == 1 ? 6 : 9;
+                    float t[NT];
+                    t[0] = ix0[0] > 0 ? raw.l[m] : 0.f;
+                    t[1] = raw.c[m].x;
+                    t[2] = raw.c[m].y;
+                    t[3] = raw.c[m].z;
+                    t[4] = raw.c[m].w;
+                    if constexpr (S == 1)
+                        t[5] = raw.r[m];
+                    else
+                    {
+                        t[5] = raw.r[m].x;
+                        t[6] = raw.r[m].y;
+                        t[7] = raw.r[m].z;
+                        t[8] = raw.r[m].w;
+                    }
+#pragma unroll
+                    for (int j = 5; j < NT; ++j) t[j] = (ix0[0] - 1 + j < p.W) ? t[j] : 0.f; // right padding
+                    const float w0 = w[m * 3], w1 = w[m * 3 + 1], w2 = w[m * 3 + 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        out[e] += t[S * e] * w0;
+                        out[e] += t[S * e + 1] * w1;
+                        out[e] += t[S * e + 2] * w2;
+                    }
+                }
+                const float b = w[9];
+                float4 v = make_float4(out[0] + b, out[1] + b, out[2] + b, out[3] + b);
+                if (p.dw_relu)
+                {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                return v;
+            }
+        }
+        __device__ Raw load(const Params& p, int krow_in_split, unsigned& ok) const
+        {
+            if constexpr (MODE >= 3)
+            {
+                const int krow = krow_in_split + koff;
+                ok = krow < p.Kd ? valid : 0u;
+                const float* plane = ptr[0] + (size_t)min(krow, p.Kd - 1) * p.HW;
+                Raw raw;
+                const int x0 = ix0[0];
+                const int xl = max(x0 - 1, 0);                        // x0 == 0: the left tap is padding, masked in finish
+                const int xr = min(x0 + 4, p.W - (MODE == 3 ? 1 : 4)); // past the row: masked in finish
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                {
+                    const int y = min(max(iy0[0] + m, 0), p.H - 1); // padding rows re-read a real row and are skipped in finish
+                    const float* row = plane + (size_t)y * p.W;
+                    raw.l[m] = row[xl];
+                    raw.c[m] = *reinterpret_cast<const float4*>(row + x0);
+                    if constexpr (MODE == 3)
+                        raw.r[m] = row[xr];
+                    else
+                        raw.r[m] = *reinterpret_cast<const float4*>(row + xr);
+                }
+                return raw;
+            }
+            else
+                return load_plain(p, krow_in_split, ok);
+        }
+        __device__ float4 load_plain(const Params& p, int krow_in_split, unsigned& ok) const
         {
             const int krow = krow_in_split + koff;
             const bool kin = krow < p.Kd;

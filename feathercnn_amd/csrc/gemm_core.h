@@ -66,7 +66,13 @@ struct GemmShape
 // Policy concept:
 //   struct Params { int batches, m_tiles, n_tiles, k_tiles; ... };
 //   struct ALoad { ALoad(const Params&, int batch, int m4); float4 load(const Params&, int krow) const; };
-//   struct BLoad { BLoad(const Params&, int batch, int n4); float4 load(const Params&, int krow, unsigned& ok) const; };
+//   struct BLoad { BLoad(const Params&, int batch, int n4); typedef ... Raw; Raw load(const Params&, int krow, unsigned& ok) const;
+//                  float4 finish(const Params&, const Raw&, int krow, const float* extra_lds) const; };
+//       (Raw = what the global loads of one request return -- float4 for a plain operand; `finish` turns it into the 4 operand values at
+//        LDS-write time, a k-tile after the loads were issued: identity for a plain operand, the 3x3 depthwise arithmetic for the fused
+//        depthwise + pointwise route)
+//   static constexpr int EXTRA_LDS_FLOATS; static void stage_extra(const Params&, float* extra_lds, int tid, int threads);
+//       (block-wide constants the B loader wants in LDS -- the depthwise taps; 0 / no-op otherwise)
 //       (m4 / n4 = first of the 4 consecutive rows / columns this thread always fetches; loads are unconditional
 //        from clamped addresses, `ok` bit e = element e is real data, zero-fill happens at LDS-write time)
 //   struct Store { Store(const Params&, int batch, int n4); void put4(const Params&, int m, float4 v) const;
@@ -100,7 +106,8 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
 {
     constexpr int BM = Shape::BM, BN = Shape::BN, BK = Shape::BK;
     // ONE LDS object (a second __shared__ object de-pipelines hipcc's waits)
-    __shared__ __attribute__((aligned(16))) float lds[Shape::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[Shape::LDS_FLOATS + Policy::EXTRA_LDS_FLOATS];
+    float* const extra = lds + Shape::LDS_FLOATS; // Policy::stage_extra's block-wide constants (behind the operand / epilogue area)
     float* const As0 = lds;               // As[buf] = As0 + buf * BK*BM
     float* const Bs0 = lds + 2 * BK * BM; // Bs[buf] = Bs0 + buf * BK*BN
 
@@ -138,7 +145,9 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     const typename Policy::ALoad aload(prm, batch, m0 + a_c4 * 4);
     const typename Policy::BLoad bload(prm, batch, n0 + b_c4 * 4);
 
-    float4 pa[Shape::A_PASSES], pb[Shape::B_PASSES];
+    typedef typename Policy::BLoad::Raw BRaw;
+    float4 pa[Shape::A_PASSES];
+    BRaw pb[Shape::B_PASSES];
     unsigned pok[Shape::B_PASSES];
     auto fetch = [&](int kt) {
 #pragma unroll
@@ -146,14 +155,14 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
 #pragma unroll
         for (int i = 0; i < Shape::B_PASSES; ++i) pb[i] = bload.load(prm, kt * BK + b_r + i * Shape::B_ROWS_PER_PASS, pok[i]);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int kt) {
 #pragma unroll
         for (int i = 0; i < Shape::A_PASSES; ++i)
             *reinterpret_cast<float4*>(&As0[buf * (BK * BM) + (a_r + i * Shape::A_ROWS_PER_PASS) * BM + a_c4 * 4]) = pa[i];
 #pragma unroll
         for (int i = 0; i < Shape::B_PASSES; ++i)
         {
-            float4 v = pb[i];
+            float4 v = bload.finish(prm, pb[i], kt * BK + b_r + i * Shape::B_ROWS_PER_PASS, extra);
             v.x = (pok[i] & 1u) ? v.x : 0.f;
             v.y = (pok[i] & 2u) ? v.y : 0.f;
             v.z = (pok[i] & 4u) ? v.z : 0.f;
@@ -174,6 +183,11 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     // (a second register set for a moment), so the block pays ONE global round trip before its first MFMA, not two.
     stamp(); // setup done
     fetch(0);
+    if (Policy::EXTRA_LDS_FLOATS > 0)
+    {
+        Policy::stage_extra(prm, extra, tid, Shape::THREADS); // behind the first operand requests; the first finish() needs it
+        __syncthreads();
+    }
     // bias of the rows this lane will store (row = .. + i*32 + q*8 + (lane >> 3)), requested behind the first operand tile
     float bias_r[Shape::TM][4];
 #pragma unroll
@@ -183,13 +197,14 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
             bias_r[i][q] = (TUNE & 2) ? Policy::bias_at(prm, m0 + wm * Shape::WTM + i * 32 + q * 8 + (lane >> 3)) : 0.f;
     if (k_tiles > 1)
     {
-        float4 qa[Shape::A_PASSES], qb[Shape::B_PASSES];
+        float4 qa[Shape::A_PASSES];
+        BRaw qb[Shape::B_PASSES];
         unsigned qok[Shape::B_PASSES];
 #pragma unroll
         for (int i = 0; i < Shape::A_PASSES; ++i) qa[i] = aload.load(prm, BK + a_r + i * Shape::A_ROWS_PER_PASS);
 #pragma unroll
         for (int i = 0; i < Shape::B_PASSES; ++i) qb[i] = bload.load(prm, BK + b_r + i * Shape::B_ROWS_PER_PASS, qok[i]);
-        stash(0); // waits for tile 0's loads only (vmcnt counts in order)
+        stash(0, 0); // waits for tile 0's loads only (vmcnt counts in order)
 #pragma unroll
         for (int i = 0; i < Shape::A_PASSES; ++i) pa[i] = qa[i];
 #pragma unroll
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
         }
     }
     else
-        stash(0);
+        stash(0, 0);
     if (TUNE & 1) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     stamp(); // k-tile 0 in LDS
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     for (int kt = 0; kt < k_tiles; ++kt)
     {
         // k-tile kt+1 (in registers since the previous iteration) -> the other LDS buffer; k-tile kt+2 -> registers
-        if (kt + 1 < k_tiles) stash(cur ^ 1);
+        if (kt + 1 < k_tiles) stash(cur ^ 1, kt + 1);
         if (kt + 2 < k_tiles && !(ABLATE & 1)) fetch(kt + 2);
 
         const float* as = As0 + cur * (BK * BM) + a_off;

@@ -8,6 +8,8 @@
 // epilogue fused into the accumulator store.  It serves exactly what AVX SelectAlgo routes to IM2COL
 // (avx/booster.cpp:294-303): 1x1 s1/s2, 7x7 s2, 3x3 with H <= 8 or C % 4 != 0, 3x3 s2; and NAIVE
 // (avx/booster.cpp:28-61, which ignores activation).
+#include <string.h>
+
 #include <algorithm>
 
 #include "gemm_core.h"
@@ -15,6 +17,8 @@
 
 namespace fhip
 {
+
+size_t depthwise_packed_floats(const fhip_conv_param& p, size_t* w12_offset); // depthwise.hip
 
 using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
@@ -473,6 +477,83 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
                            g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu);
         FHIP_CHECK_HIP(hipGetLastError());
     }
+    return FHIP_OK;
+}
+
+// ---- depthwise 3x3 fused into the 1x1 convolution that consumes it (MobileNet's dw -> pw pairs) -------------------------------
+// out = act_pw(W_pw * act_dw(dw3x3(in) + b_dw) + b_pw): ConvGemmPolicy<3> computes the pointwise GEMM's B operand from the depthwise
+// layer's INPUT, so the depthwise output (a tensor as large as the pair's input) is never written nor read.
+bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch)
+{
+    const int s = dw.stride_h > 0 ? dw.stride_h : 1;
+    if (dw.group != dw.input_channels || dw.group < 1 || dw.kernel_h != 3 || dw.kernel_w != 3 || dw.stride_w != dw.stride_h || (s != 1 && s != 2)) return false;
+    if (dw.pad_left != 1 || dw.pad_top != 1 || dw.input_channels > kDwFusedMaxC) return false;
+    if ((dw.input_w % 4) || (dw.output_w % 4) || dw.output_w * s != dw.input_w) return false; // aligned patch loads, no ragged right edge
+    if (pw.group != 1 || pw.kernel_h != 1 || pw.kernel_w != 1 || (pw.stride_h > 1) || (pw.stride_w > 1) || pw.pad_left || pw.pad_right || pw.pad_top ||
+        pw.pad_bottom)
+        return false;
+    if (pw.input_channels != dw.input_channels || pw.input_h != dw.output_h || pw.input_w != dw.output_w) return false;
+    if (pw.output_h != dw.output_h || pw.output_w != dw.output_w) return false;
+    const long long ntot = (long long)batch * pw.output_h * pw.output_w;
+    return batch >= 1 && ntot <= 0x7fffff00LL && !conv_narrow_n(ntot) && igemm_split(pw, batch) == 1;
+}
+
+int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch, float* out, const float* in, const float* dw_packed,
+                 const float* dw_bias, const float* pw_packed, const float* pw_bias, hipStream_t s)
+{
+    if (!dwpw_applicable(dw, pw, batch)) return fail(FHIP_E_UNSUPPORTED, "this depthwise + pointwise pair cannot be fused (fhip_conv_can_fuse_dw_pw)");
+    if (dw.bias_term && !dw_bias) return fail(FHIP_E_BADARG, "depthwise bias_term set but its bias is NULL");
+    if (pw.bias_term && !pw_bias) return fail(FHIP_E_BADARG, "pointwise bias_term set but its bias is NULL");
+    ConvGemmParams g;
+    memset(&g, 0, sizeof g);
+    g.batches = 1;
+    g.Wt = pw_packed;
+    g.in = in;
+    g.out = out;
+    g.bias = pw_bias;
+    g.C = pw.input_channels;
+    g.K = pw.output_channels;
+    g.H = dw.input_h;
+    g.W = dw.input_w;
+    g.OH = pw.output_h;
+    g.OW = pw.output_w;
+    g.SH = g.SW = 1;
+    g.KH = g.KW = 1;
+    g.Kd = g.C;
+    int kdp;
+    igemm_packed_dims(pw, &kdp, &g.Kp);
+    g.Kdp = kdp;
+    g.bm = conv_small_m(g.K) ? 64 : 128;
+    g.OHW = g.OH * g.OW;
+    g.HW = g.H * g.W;
+    g.KHW = 1;
+    g.Ntot = (int)((long long)batch * g.OHW);
+    g.has_bias = pw.bias_term != 0;
+    g.relu = pw.activation == FHIP_ACT_RELU;
+    g.split_k = 1;
+    g.k_tiles = kdp / kConvKTile;
+    size_t w12 = 0;
+    depthwise_packed_floats(dw, &w12);
+    g.dw_w12 = dw_packed + w12;
+    g.dw_bias = dw.bias_term ? dw_bias : nullptr;
+    g.dw_stride = dw.stride_h > 0 ? dw.stride_h : 1;
+    g.dw_relu = dw.activation == FHIP_ACT_RELU;
+    StageTimer tm(FHIP_STAGE_IGEMM, s);
+    // three blocks per CU (168 VGPRs): the in-flight depthwise patches take 18 / 27 registers per operand request
+    using FusedBig = GemmShape<128, 64, 16, 2, 2, 3>;
+    using FusedSmallM = GemmShape<64, 128, 16, 1, 4, 3>;
+    using FusedSmallM2 = GemmShape<64, 128, 16, 1, 4, 2>; // two operand requests of 27 registers each in flight
+    if (conv_small_m(g.K))
+    {
+        if (g.dw_stride == 1) launch<FusedSmallM, 3>(g, s);
+        else launch<FusedSmallM2, 4>(g, s);
+    }
+    else
+    {
+        if (g.dw_stride == 1) launch<FusedBig, 3>(g, s);
+        else launch<FusedBig, 4>(g, s);
+    }
+    FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
 

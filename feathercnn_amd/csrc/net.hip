@@ -340,6 +340,7 @@ struct Layer
     virtual size_t arena_bytes() const { return 0; }
     virtual int algo() const { return -1; }
     virtual const fhip_conv_param* conv_param() const { return nullptr; }
+    virtual const fhip_conv_param* fused_pointwise() const { return nullptr; } // the 1x1 convolution a depthwise layer runs fused with
 };
 
 struct Net
@@ -409,6 +410,12 @@ struct ConvLayer : Layer
     // fusion level 2: a following Eltwise SUM (+ReLU) with an earlier blob is absorbed: top = act(conv + bias + residual)
     Blob* residual = nullptr;
     bool res_fast = false;
+    // fusion level 2: this is a 3x3 depthwise layer and the 1x1 convolution that is its only consumer was absorbed (`pw` owns its
+    // parameters, weights and further fusions); when the pair qualifies at the current shape the two run as ONE kernel
+    // (fhip_conv_forward_dw_pw) and the depthwise output never exists, else dw -> `mid` -> pw one after the other
+    std::unique_ptr<ConvLayer> pw;
+    bool pair_fast = false;
+    DeviceVec mid;
 
     ConvLayer()
     {
@@ -464,6 +471,27 @@ struct ConvLayer : Layer
         if (p.output_h < 1 || p.output_w < 1) return failf(NET_E_SHAPE, "layer %s: empty output", name.c_str());
         int rc = net->tuned_selection ? fhip_conv_select_algo_tuned(&p, &algo_) : fhip_conv_select_algo(&p, &algo_);
         if (rc) return rc;
+        if (pw)
+        {
+            // the absorbed 1x1 convolution reshapes against a stand-in for the depthwise output, then takes over this layer's top
+            Blob dwout;
+            dwout.n = b->n;
+            dwout.c = p.output_channels;
+            dwout.h = p.output_h;
+            dwout.w = p.output_w;
+            pw->bottoms.assign(1, &dwout);
+            pw->tops = tops;
+            pw->net = net;
+            rc = pw->Reshape();
+            pw->bottoms.clear();
+            if (rc) return rc;
+            pair_fast = fhip_conv_can_fuse_dw_pw(&p, &pw->p, b->n) != 0 && !pw->fuse_pool && !pw->residual && pw->algo_ == FHIP_IM2COL;
+            if (!pair_fast && (rc = mid.resize((size_t)b->n * p.output_channels * p.output_h * p.output_w * sizeof(float)))) return rc;
+            size_t bb = 0;
+            if ((rc = fhip_conv_get_buffer_size(&p, algo_, b->n, &bb, &packed_bytes))) return rc;
+            buffer_bytes = std::max(bb, pw->buffer_bytes);
+            return 0;
+        }
         res_fast = residual && fhip_conv_can_fuse_residual(&p, algo_) != 0;
         if (residual && (residual->n != b->n || residual->c != p.output_channels || residual->h != p.output_h || residual->w != p.output_w))
             return failf(NET_E_SHAPE, "Shape mismatch among bottoms of layer %s.", name.c_str());
@@ -485,6 +513,11 @@ struct ConvLayer : Layer
     }
     int Init(hipStream_t s) override
     {
+        if (pw)
+        {
+            const int rc = pw->Init(s);
+            if (rc) return rc;
+        }
         if (inited_algo == algo_ && packed.bytes == packed_bytes) return 0;
         const int K = p.output_channels;
         std::vector<float> w = w_host, b = b_host;
@@ -518,6 +551,26 @@ struct ConvLayer : Layer
     int Forward(hipStream_t s) override
     {
         const float* b = p.bias_term ? bias.d : nullptr;
+        if (pw)
+        {
+            const float* pb = pw->p.bias_term ? pw->bias.d : nullptr;
+            if (pair_fast)
+                return fhip_conv_forward_dw_pw(&p, &pw->p, bottoms[0]->n, tops[0]->data, bottoms[0]->data, packed.d, b, pw->packed.d, pb, s);
+            int rc = fhip_conv_forward(&p, algo_, bottoms[0]->n, mid.d, bottoms[0]->data, packed.d, (float*)net->arena.d, b, s);
+            if (rc) return rc;
+            Blob dwout; // stand-in for the depthwise output the pair no longer has a blob for
+            dwout.n = bottoms[0]->n;
+            dwout.c = p.output_channels;
+            dwout.h = p.output_h;
+            dwout.w = p.output_w;
+            dwout.data = mid.d;
+            pw->bottoms.assign(1, &dwout);
+            pw->tops = tops;
+            rc = pw->Forward(s);
+            pw->bottoms.clear();
+            dwout.data = nullptr;
+            return rc;
+        }
         if (residual)
         {
             if (residual->alias) residual->data = residual->alias->data;
@@ -541,12 +594,13 @@ struct ConvLayer : Layer
     // absorb `elt` = Eltwise SUM of this layer's top and `other` (a blob produced earlier in the layer list)
     bool FuseResidual(Blob* other)
     {
-        if (fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
+        if (pw || fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
         residual = other;
         bottoms.push_back(other); // so that dependency scans (fusion, branch concurrency) see the second input
         return true;
     }
-    size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes; }
+    size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + (pw ? pw->weight_bytes() : 0); }
+    const fhip_conv_param* fused_pointwise() const override { return (pw && pair_fast) ? &pw->p : nullptr; }
     size_t arena_bytes() const override { return buffer_bytes; }
     const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
@@ -796,7 +850,16 @@ struct ScaleLayer : AffineLayer
 
 int ConvLayer::Fuse(Layer* next, int level)
 {
+    if (pw) return pw->Fuse(next, level) == 1 ? 1 : 0; // behind the absorbed 1x1 convolution: its own fusions
     if (fuse_pool) return 0; // nothing is absorbed behind the pooling
+    if (level >= 2 && !residual && next->type == "Convolution" && p.group == p.input_channels && p.group > 1 && p.kernel_h == 3 && p.kernel_w == 3)
+    {
+        // depthwise 3x3 -> 1x1 convolution: the pair becomes one layer (one kernel where fhip_conv_can_fuse_dw_pw allows it)
+        const fhip_conv_param& q = static_cast<ConvLayer*>(next)->p;
+        if (q.group != 1 || q.kernel_h != 1 || q.kernel_w != 1 || q.stride_h != 1 || q.stride_w != 1 || q.pad_left || q.pad_right || q.pad_top || q.pad_bottom)
+            return 0;
+        return 2; // the pass hands `next` over (fuse_layers)
+    }
     if (residual && next->type != "ReLU") return 0; // behind the residual add only its ReLU
     if (level >= 2 && next->type == "Pooling")
     {
@@ -1114,7 +1177,9 @@ static void fuse_layers(Net& net)
                 continue;
             }
             if (nx->bottoms.size() != 1 || nx->tops.size() != 1) break;
-            if (cur->Fuse(nx, net.fusion) != 1) break;
+            const int fr = cur->Fuse(nx, net.fusion);
+            if (fr != 1 && fr != 2) break;
+            if (fr == 2) static_cast<ConvLayer*>(cur)->pw.reset(static_cast<ConvLayer*>(net.layers[consumer].release())); // adopted, not dropped
             top->fused_away = true;
             cur->tops[0] = nx->tops[0];
             net.layers.erase(net.layers.begin() + consumer);
@@ -1455,6 +1520,16 @@ int fhip_net_layer_conv_param(fhip_net* n, int index, fhip_conv_param* param, in
     if (!cp) return fail(FHIP_E_BADARG, "not a convolution layer");
     *param = *cp;
     if (batch) *batch = l->bottoms.empty() ? 0 : l->bottoms[0]->n;
+    return FHIP_OK;
+}
+
+int fhip_net_layer_fused_pointwise(fhip_net* n, int index, fhip_conv_param* param)
+{
+    NET_GUARD(n);
+    if (index < 0 || index >= (int)n->impl.layers.size() || !param) return fail(FHIP_E_BADARG, "layer index out of range");
+    const fhip_conv_param* cp = n->impl.layers[index]->fused_pointwise();
+    if (!cp) return fail(FHIP_E_BADARG, "no fused pointwise convolution in this layer");
+    *param = *cp;
     return FHIP_OK;
 }
 

@@ -18,6 +18,8 @@ struct WinoGemmPolicy
         float* M;
         int C, K, Cp, Kp, Pp;
     };
+    static constexpr int EXTRA_LDS_FLOATS = 0;
+    static __device__ void stage_extra(const Params&, float*, int, int) {}
     static __device__ int k_count(const Params& p, int) { return p.k_tiles; }
     static __device__ float bias_at(const Params&, int) { return 0.f; } // the bias is the output transform's business
     struct ALoad
@@ -31,6 +33,8 @@ struct WinoGemmPolicy
     };
     struct BLoad
     {
+        typedef float4 Raw;
+        __device__ float4 finish(const Params&, const Raw& r, int, const float*) const { return r; }
         const float* base;
         __device__ BLoad(const Params& p, int xi, int n4) : base(p.V + (size_t)xi * p.C * p.Pp + n4) {}
         __device__ float4 load(const Params& p, int krow, unsigned& ok) const

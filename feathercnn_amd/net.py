@@ -123,6 +123,15 @@ class Net:
                 out[i] = (p, b.value)
         return out
 
+    def fused_pointwise(self):
+        """{layer index: fhip_conv_param of the 1x1 convolution a depthwise layer runs fused with} (fusion level 2)."""
+        out = {}
+        for i in range(self._lib.fhip_net_layer_count(self._h)):
+            p = _lib.fhip_conv_param()
+            if self._lib.fhip_net_layer_fused_pointwise(self._h, i, ctypes.byref(p)) == 0:
+                out[i] = p
+        return out
+
     def forward_timed(self):
         """One eager forward with HIP events around every layer: [(type, name, algo, ms)]."""
         n = self._lib.fhip_net_layer_count(self._h)

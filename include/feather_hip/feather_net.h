@@ -47,6 +47,20 @@ FHIP_API int fhip_conv_can_fuse_residual(const fhip_conv_param* param, int algo)
 FHIP_API int fhip_conv_forward_residual(const fhip_conv_param* param, int algo, int batch, float* output, const float* input,
                                         const float* packed, float* buffer, const float* bias, const float* residual, void* stream);
 
+/* A 3x3 depthwise convolution (+bias, +ReLU as `dw` says) followed by the 1x1 convolution that is its only consumer (+bias, +ReLU as
+ * `pw` says), fused: output = act_pw(W_pw * act_dw(dw(input) + b_dw) + b_pw).  The pointwise GEMM computes its column operand from
+ * the depthwise layer's INPUT on the fly, so the depthwise output -- a tensor as large as the pair's input -- never reaches HBM
+ * (MobileNet-V1's first dw/pw pairs are HBM bound).  Equal to two ConvLayer::Forward calls of the reference (conv_layer.h:141-150
+ * with DEPTHWISE_Forward, avx/booster.cpp:136-160, then IM2COL_Forward, :83-102).
+ *   dw_packed / pw_packed: what fhip_conv_init produced for FHIP_DEPTHWISE / FHIP_IM2COL; no scratch buffer is needed.
+ * fhip_conv_can_fuse_dw_pw returns 1 when the pair qualifies: depthwise 3x3, stride 1 or 2, pad_left = pad_top = 1, input and
+ * output widths multiples of 4 with output_w * stride == input_w, at most 256 channels; pointwise 1x1 stride 1 unpadded on exactly
+ * the depthwise output, large enough not to run split-K at this batch.  Otherwise fhip_conv_forward_dw_pw returns FHIP_E_UNSUPPORTED
+ * (run the two layers one after the other). */
+FHIP_API int fhip_conv_can_fuse_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch);
+FHIP_API int fhip_conv_forward_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch, float* output, const float* input,
+                                     const float* dw_packed, const float* dw_bias, const float* pw_packed, const float* pw_bias, void* stream);
+
 /* PoolingLayer, layers/pooling_layer.h:90-131 (fields as its LoadParam reads them). */
 typedef struct fhip_pool_param
 {
@@ -122,6 +136,9 @@ FHIP_API int fhip_net_layer_info(fhip_net* net, int index, char* type, char* nam
  * the batch of its input blob; FHIP_E_BADARG for any other layer type.  (bench.py prices each layer's kernel against its roofline
  * with ConvParam::GetFLOPS, booster.h:145-148.) */
 FHIP_API int fhip_net_layer_conv_param(fhip_net* net, int index, fhip_conv_param* param, int* batch);
+/* Fusion level 2 runs a 3x3 depthwise layer and the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw): for such a
+ * layer, fhip_net_layer_conv_param describes the depthwise half and this returns the pointwise half; FHIP_E_BADARG otherwise. */
+FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_param* param);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

@@ -146,7 +146,31 @@ int main(int argc, char** argv)
                                 }
                             }});
         }
-        for (int floats : {1568, 3136, 6272, 12544})
+        if (cs.S == 1 && q.OH % 7 == 0)
+        {
+            const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
+            const int yblocks = q.OH / 7, xvecs = q.OW / vx;
+            const long long total = (long long)q.planes * yblocks * xvecs;
+            const int grid = (int)std::min(8192LL, (total + 255) / 256);
+            vars.push_back({"direct R=7", [=] {
+                                if (vx == 4) hipLaunchKernelGGL((depthwise3x3_direct_kernel<1, 4, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                                else if (vx == 2) hipLaunchKernelGGL((depthwise3x3_direct_kernel<1, 2, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                                else hipLaunchKernelGGL((depthwise3x3_direct_kernel<1, 1, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                            }});
+        }
+        if (cs.S == 2 && q.OH % 7 == 0)
+        {
+            const int vx = ((q.W % 4) == 0 && (q.OW % 4) == 0) ? 4 : (((q.W % 2) == 0 && (q.OW % 2) == 0) ? 2 : 1);
+            const int yblocks = q.OH / 7, xvecs = q.OW / vx;
+            const long long total = (long long)q.planes * yblocks * xvecs;
+            const int grid = (int)std::min(8192LL, (total + 255) / 256);
+            vars.push_back({"direct s2 R=7", [=] {
+                                if (vx == 4) hipLaunchKernelGGL((depthwise3x3_direct_kernel<2, 4, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                                else if (vx == 2) hipLaunchKernelGGL((depthwise3x3_direct_kernel<2, 2, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                                else hipLaunchKernelGGL((depthwise3x3_direct_kernel<2, 1, 7>), dim3(grid), dim3(256), 0, 0, q, yblocks, xvecs, total);
+                            }});
+        }
+        for (int floats : {3136})
         {
             int cp = std::max(1, floats / HW);
             if (HW % 4) cp = std::max(4, cp / 4 * 4);

@@ -254,10 +254,16 @@ def attribute(net, reps):
             row.update({"C": p.input_channels, "K": p.output_channels, "H": p.input_h, "k": p.kernel_h, "s": p.stride_h, "batch": n,
                         "direct_tflops": round(fl / max(ms, 1e-9) / 1e9, 2)})
             a_id = algo_id.get(algo)
-            if i in fused_pw:
+            if i in fused_pw and not fused_pw[i][1]:
+                # absorbed pair that runs its two kernels one after the other at this shape: one layer time for both, priced by neither roofline
+                q = fused_pw[i][0]
+                direct += 2.0 * q.output_channels * q.input_channels * q.output_h * q.output_w * n
+                row["sequential_pair_K"] = q.output_channels
+                dw_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + p.output_channels * p.output_h * p.output_w) * n + 40.0 * p.input_channels
+            elif i in fused_pw:
                 # a 3x3 depthwise layer and the 1x1 convolution behind it running as ONE kernel (fhip_conv_forward_dw_pw): the pair's
                 # compulsory bytes are its input and its output, its matrix work the pointwise GEMM
-                q = fused_pw[i]
+                q = fused_pw[i][0]
                 pfl = 2.0 * q.output_channels * q.input_channels * q.output_h * q.output_w * n
                 direct += pfl
                 fz_flops += pfl
@@ -291,9 +297,10 @@ def attribute(net, reps):
         r["layer_frac_min"] = min(pw_rows)
         r["layer_frac_mean"] = round(sum(pw_rows) / len(pw_rows), 4)
         roofs.append(r)
-    if dw_bytes and dw_ms:
-        roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, dw_ms, "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C summed "
-                                  "over the depthwise layers of a step / sum of their HIP-event durations"))
+    if dw_bytes and stage.get("depthwise"):
+        roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, stage["depthwise"], "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C "
+                                  "summed over the depthwise launches of a step (the layers fused into their 1x1 convolution have none) / sum of "
+                                  "their HIP-event durations on the launch stream"))
     if fz_ms:
         roofs.append(roofline_hbm("fused depthwise 3x3 + 1x1: gemm_mfma_kernel<ConvGemmPolicy<3|4>>", fz_bytes, fz_ms, "input of the depthwise + output "
                                   "of the pointwise layer (the depthwise output never exists) summed over the fused pairs / their HIP-event durations"))

@@ -89,7 +89,7 @@ SIGNATURES = {
     "fhip_net_layer_count": (_I, [_V]),
     "fhip_net_layer_info": (_I, [_V, _I, ctypes.c_char_p, ctypes.c_char_p, _I, _PI]),
     "fhip_net_layer_conv_param": (_I, [_V, _I, _P, _PI]),
-    "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P]),
+    "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P, _PI]),
     "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
     "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }

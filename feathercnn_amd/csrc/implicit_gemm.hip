@@ -494,6 +494,13 @@ bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int b
         return false;
     if (pw.input_channels != dw.input_channels || pw.input_h != dw.output_h || pw.input_w != dw.output_w) return false;
     if (pw.output_h != dw.output_h || pw.output_w != dw.output_w) return false;
+    // Worth it?  The fused kernel costs ~1.4x the pointwise GEMM alone (the 36 FMAs per operand vector issue next to the MFMAs), the
+    // two-kernel form costs the GEMM plus an HBM-bound depthwise pass of 4*C*(HWin + HWout)*N bytes: with the GEMM at ~60 % of the
+    // fp32 MFMA peak and HBM at ~5 TB/s the fused form wins while (HWin / HWout + 1) * 38 / K > 0.45, i.e. K < 160 behind a stride-1
+    // and K < 400 behind a stride-2 depthwise layer.  Measured on MobileNet-V1 b256: C64->K128 s2 0.374 -> 0.310 ms,
+    // C128->K128 s1 0.455 -> 0.369, C128->K256 s2 0.250 -> 0.238; C256->K256 s1 0.358 -> 0.337 and C32->K64 (64-row tile, two operand
+    // requests per thread) 0.414 -> 0.404 are inside the noise and stay two kernels.
+    if (pw.output_channels <= 64 || pw.output_channels >= (s == 1 ? 160 : 400)) return false;
     const long long ntot = (long long)batch * pw.output_h * pw.output_w;
     return batch >= 1 && ntot <= 0x7fffff00LL && !conv_narrow_n(ntot) && igemm_split(pw, batch) == 1;
 }
@@ -541,18 +548,8 @@ int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch
     StageTimer tm(FHIP_STAGE_IGEMM, s);
     // three blocks per CU (168 VGPRs): the in-flight depthwise patches take 18 / 27 registers per operand request
     using FusedBig = GemmShape<128, 64, 16, 2, 2, 3>;
-    using FusedSmallM = GemmShape<64, 128, 16, 1, 4, 3>;
-    using FusedSmallM2 = GemmShape<64, 128, 16, 1, 4, 2>; // two operand requests of 27 registers each in flight
-    if (conv_small_m(g.K))
-    {
-        if (g.dw_stride == 1) launch<FusedSmallM, 3>(g, s);
-        else launch<FusedSmallM2, 4>(g, s);
-    }
-    else
-    {
-        if (g.dw_stride == 1) launch<FusedBig, 3>(g, s);
-        else launch<FusedBig, 4>(g, s);
-    }
+    if (g.dw_stride == 1) launch<FusedBig, 3>(g, s); // K > 64 (dwpw_applicable): always the 128-row tile
+    else launch<FusedBig, 4>(g, s);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }

@@ -340,7 +340,7 @@ struct Layer
     virtual size_t arena_bytes() const { return 0; }
     virtual int algo() const { return -1; }
     virtual const fhip_conv_param* conv_param() const { return nullptr; }
-    virtual const fhip_conv_param* fused_pointwise() const { return nullptr; } // the 1x1 convolution a depthwise layer runs fused with
+    virtual const fhip_conv_param* fused_pointwise(int*) const { return nullptr; } // the 1x1 convolution a depthwise layer absorbed
 };
 
 struct Net
@@ -600,7 +600,11 @@ struct ConvLayer : Layer
         return true;
     }
     size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + (pw ? pw->weight_bytes() : 0); }
-    const fhip_conv_param* fused_pointwise() const override { return (pw && pair_fast) ? &pw->p : nullptr; }
+    const fhip_conv_param* fused_pointwise(int* one_kernel) const override
+    {
+        if (one_kernel) *one_kernel = pair_fast ? 1 : 0;
+        return pw ? &pw->p : nullptr;
+    }
     size_t arena_bytes() const override { return buffer_bytes; }
     const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
@@ -852,12 +856,15 @@ int ConvLayer::Fuse(Layer* next, int level)
 {
     if (pw) return pw->Fuse(next, level) == 1 ? 1 : 0; // behind the absorbed 1x1 convolution: its own fusions
     if (fuse_pool) return 0; // nothing is absorbed behind the pooling
-    if (level >= 2 && !residual && next->type == "Convolution" && p.group == p.input_channels && p.group > 1 && p.kernel_h == 3 && p.kernel_w == 3)
+    if (level >= 2 && !residual && next->type == "Convolution" && p.group == p.input_channels && p.group > 1 && p.group <= 256 && p.kernel_h == 3 &&
+        p.kernel_w == 3 && p.stride_h == p.stride_w && (p.stride_h == 1 || p.stride_h == 2) && p.pad_left == 1 && p.pad_top == 1)
     {
-        // depthwise 3x3 -> 1x1 convolution: the pair becomes one layer (one kernel where fhip_conv_can_fuse_dw_pw allows it)
+        // depthwise 3x3 (at most 256 channels: fhip_conv_can_fuse_dw_pw's structural conditions) -> 1x1 convolution: the pair becomes one
+        // layer -- one kernel where the shapes qualify too, else the two kernels one after the other inside this layer
         const fhip_conv_param& q = static_cast<ConvLayer*>(next)->p;
         if (q.group != 1 || q.kernel_h != 1 || q.kernel_w != 1 || q.stride_h != 1 || q.stride_w != 1 || q.pad_left || q.pad_right || q.pad_top || q.pad_bottom)
             return 0;
+        if (q.output_channels <= 64 || q.output_channels >= (p.stride_h == 1 ? 160 : 400)) return 0; // fhip_conv_can_fuse_dw_pw's profitable range
         return 2; // the pass hands `next` over (fuse_layers)
     }
     if (residual && next->type != "ReLU") return 0; // behind the residual add only its ReLU
@@ -1523,12 +1530,12 @@ int fhip_net_layer_conv_param(fhip_net* n, int index, fhip_conv_param* param, in
     return FHIP_OK;
 }
 
-int fhip_net_layer_fused_pointwise(fhip_net* n, int index, fhip_conv_param* param)
+int fhip_net_layer_fused_pointwise(fhip_net* n, int index, fhip_conv_param* param, int* one_kernel)
 {
     NET_GUARD(n);
     if (index < 0 || index >= (int)n->impl.layers.size() || !param) return fail(FHIP_E_BADARG, "layer index out of range");
-    const fhip_conv_param* cp = n->impl.layers[index]->fused_pointwise();
-    if (!cp) return fail(FHIP_E_BADARG, "no fused pointwise convolution in this layer");
+    const fhip_conv_param* cp = n->impl.layers[index]->fused_pointwise(one_kernel);
+    if (!cp) return fail(FHIP_E_BADARG, "no pointwise convolution was absorbed into this layer");
     *param = *cp;
     return FHIP_OK;
 }

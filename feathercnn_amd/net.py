@@ -124,12 +124,12 @@ class Net:
         return out
 
     def fused_pointwise(self):
-        """{layer index: fhip_conv_param of the 1x1 convolution a depthwise layer runs fused with} (fusion level 2)."""
+        """{layer index: (fhip_conv_param of the 1x1 convolution a depthwise layer absorbed, runs_as_one_kernel)} (fusion level 2)."""
         out = {}
         for i in range(self._lib.fhip_net_layer_count(self._h)):
-            p = _lib.fhip_conv_param()
-            if self._lib.fhip_net_layer_fused_pointwise(self._h, i, ctypes.byref(p)) == 0:
-                out[i] = p
+            p, one = _lib.fhip_conv_param(), ctypes.c_int()
+            if self._lib.fhip_net_layer_fused_pointwise(self._h, i, ctypes.byref(p), ctypes.byref(one)) == 0:
+                out[i] = (p, bool(one.value))
         return out
 
     def forward_timed(self):

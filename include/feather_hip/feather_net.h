@@ -55,8 +55,9 @@ FHIP_API int fhip_conv_forward_residual(const fhip_conv_param* param, int algo, 
  *   dw_packed / pw_packed: what fhip_conv_init produced for FHIP_DEPTHWISE / FHIP_IM2COL; no scratch buffer is needed.
  * fhip_conv_can_fuse_dw_pw returns 1 when the pair qualifies: depthwise 3x3, stride 1 or 2, pad_left = pad_top = 1, input and
  * output widths multiples of 4 with output_w * stride == input_w, at most 256 channels; pointwise 1x1 stride 1 unpadded on exactly
- * the depthwise output, large enough not to run split-K at this batch.  Otherwise fhip_conv_forward_dw_pw returns FHIP_E_UNSUPPORTED
- * (run the two layers one after the other). */
+ * the depthwise output, large enough not to run split-K at this batch, and with 64 < output_channels < 160 (stride 1) / 400 (stride 2)
+ * -- the range in which one kernel beats two on this chip.  Otherwise fhip_conv_forward_dw_pw returns FHIP_E_UNSUPPORTED (run the two
+ * layers one after the other). */
 FHIP_API int fhip_conv_can_fuse_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch);
 FHIP_API int fhip_conv_forward_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw, int batch, float* output, const float* input,
                                      const float* dw_packed, const float* dw_bias, const float* pw_packed, const float* pw_bias, void* stream);
@@ -136,9 +137,11 @@ FHIP_API int fhip_net_layer_info(fhip_net* net, int index, char* type, char* nam
  * the batch of its input blob; FHIP_E_BADARG for any other layer type.  (bench.py prices each layer's kernel against its roofline
  * with ConvParam::GetFLOPS, booster.h:145-148.) */
 FHIP_API int fhip_net_layer_conv_param(fhip_net* net, int index, fhip_conv_param* param, int* batch);
-/* Fusion level 2 runs a 3x3 depthwise layer and the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw): for such a
- * layer, fhip_net_layer_conv_param describes the depthwise half and this returns the pointwise half; FHIP_E_BADARG otherwise. */
-FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_param* param);
+/* Fusion level 2 makes a 3x3 depthwise layer (<= 256 channels, stride 1 / 2, pad 1) and the 1x1 convolution behind it ONE layer: for
+ * such a layer, fhip_net_layer_conv_param describes the depthwise half and this returns the pointwise half; *one_kernel = 1 when the
+ * pair runs as one kernel at the current shape (fhip_conv_forward_dw_pw), 0 when it runs the two kernels one after the other.
+ * FHIP_E_BADARG for every other layer. */
+FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_param* param, int* one_kernel);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

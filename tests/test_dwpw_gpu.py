@@ -13,9 +13,10 @@ TOL = 1e-4
 
 # C, K, H, W, stride, batch, dw_act, pw_act, dw_bias, pw_bias
 # (a pointwise layer with >= 16 k-tiles and < 512 output tiles runs split-K and is not fusable: the C = 256 case uses batch 24)
-PAIRS = [(32, 64, 112, 112, 1, 2, 1, 1, 1, 1), (64, 128, 112, 112, 2, 2, 1, 1, 1, 1), (128, 128, 56, 56, 1, 3, 1, 1, 1, 1), (128, 256, 56, 56, 2, 2, 1, 1, 1, 1),
-         (256, 256, 28, 28, 1, 24, 1, 1, 1, 1), (16, 24, 16, 16, 1, 3, 0, 1, 0, 1), (8, 200, 24, 16, 2, 2, 1, 0, 1, 0), (12, 40, 10, 16, 1, 2, 0, 0, 0, 0),
-         (20, 64, 9, 8, 1, 5, 1, 1, 1, 1), (40, 72, 6, 16, 2, 3, 1, 1, 0, 1), (128, 32, 12, 12, 1, 2, 1, 1, 1, 1), (3, 130, 20, 24, 1, 1, 1, 1, 1, 1)]
+# and only 64 < K < 160 (stride 1) / 400 (stride 2) is fused: the range where one kernel beats two)
+PAIRS = [(32, 96, 112, 112, 1, 2, 1, 1, 1, 1), (64, 128, 112, 112, 2, 2, 1, 1, 1, 1), (128, 128, 56, 56, 1, 3, 1, 1, 1, 1), (128, 256, 56, 56, 2, 2, 1, 1, 1, 1),
+         (256, 144, 28, 28, 1, 24, 1, 1, 1, 1), (16, 72, 16, 16, 1, 3, 0, 1, 0, 1), (8, 200, 24, 16, 2, 2, 1, 0, 1, 0), (12, 100, 10, 16, 1, 2, 0, 0, 0, 0),
+         (20, 65, 9, 8, 1, 5, 1, 1, 1, 1), (40, 72, 6, 16, 2, 3, 1, 1, 0, 1), (128, 390, 12, 24, 2, 2, 1, 1, 1, 1), (3, 130, 20, 24, 1, 1, 1, 1, 1, 1)]
 
 
 def _layers(cuda, c, k, h, w, s, batch, dw_act, pw_act, dw_bias, pw_bias, seed):
@@ -68,10 +69,11 @@ def test_fused_pair_equals_the_two_layers(cfg, cuda, port):
 def test_pairs_that_do_not_qualify_are_refused(cuda):
     from feathercnn_amd import _lib
     lib = _lib.load_library()
-    bad = [(32, 64, 14, 14, 1, 2, 1, 1, 1, 1),    # W % 4 != 0
-           (300, 64, 16, 16, 1, 2, 1, 1, 1, 1),   # more channels than the LDS tap table holds
-           (32, 64, 16, 16, 1, 1, 1, 1, 1, 1)]    # so few columns that the pointwise layer runs split-K / the narrow tile
-    for cfg in bad[:2]:
+    bad = [(32, 96, 14, 14, 1, 2, 1, 1, 1, 1),    # W % 4 != 0
+           (300, 96, 16, 16, 1, 2, 1, 1, 1, 1),   # more channels than the LDS tap table holds
+           (32, 64, 16, 16, 1, 2, 1, 1, 1, 1),    # K <= 64: two kernels are as fast
+           (32, 256, 16, 16, 1, 2, 1, 1, 1, 1)]   # K >= 160 behind a stride-1 depthwise layer: the GEMM dominates, two kernels are as fast
+    for cfg in bad:
         ld, lp, xt, _ = _layers(cuda, *cfg, seed=1)
         cd, cp = ld.param._c(), lp.param._c()
         assert lib.fhip_conv_can_fuse_dw_pw(ctypes.byref(cd), ctypes.byref(cp), cfg[5]) == 0
@@ -84,17 +86,19 @@ def test_pairs_that_do_not_qualify_are_refused(cuda):
 
 def test_net_fusion_level_2_fuses_the_pairs_and_matches_level_1(cuda):
     """MobileNet-style stack through the Net runtime: level 2 runs the qualifying pairs as one kernel (fhip_net_layer_fused_pointwise
-    reports them), the 14-pixel pair (W % 4 != 0) falls back to dw -> pw inside the fused layer; both equal level 1."""
+    reports them), the others (K = 64; a 6-pixel plane) fall back to dw -> pw inside the fused layer; both equal level 1."""
     from feathercnn_amd import model_zoo
     from feathercnn_amd.net import Net
     g = model_zoo.GraphBuilder(3)
     x = g.input("data", 3, 64, 64)
     x = g.conv_bn_relu("conv1", x, 3, 16, 3, 2, 1)
-    for i, (c, k, s) in enumerate([(16, 32, 1), (32, 64, 2), (64, 64, 1), (64, 128, 2), (128, 128, 1)]):   # 32, 32->16, 16, 16->8, 8 pixels
+    for i, (c, k, s) in enumerate([(16, 96, 1), (96, 128, 2), (128, 64, 1), (64, 128, 2), (128, 128, 1)]):   # 32, 32->16, 16, 16->8, 8 pixels
         x = g.conv_bn_relu(f"dw{i}", x, c, c, 3, s, 1, group=c)
         x = g.conv_bn_relu(f"pw{i}", x, c, k, 1, 1, 0)
-    x = g.conv_bn_relu("dw_odd", x, 128, 128, 3, 1, 0, group=128)   # 8 -> 6 pixels: pad 0, does not qualify
+    x = g.conv_bn_relu("dw_odd", x, 128, 128, 3, 1, 0, group=128)   # 8 -> 6 pixels: pad 0, is not absorbed
     x = g.conv_bn_relu("pw_odd", x, 128, 32, 1, 1, 0)
+    x = g.conv_bn_relu("dw_seq", x, 32, 32, 3, 1, 1, group=32)      # 6 pixels: absorbed, but W % 4 != 0 -> the two kernels in one layer
+    x = g.conv_bn_relu("pw_seq", x, 32, 96, 1, 1, 0)
     p, b = g.finish()
     img = np.random.default_rng(8).uniform(-1, 1, (4, 3, 64, 64)).astype(np.float32)
     outs = {}
@@ -104,10 +108,11 @@ def test_net_fusion_level_2_fuses_the_pairs_and_matches_level_1(cuda):
         net.LoadWeights(b)
         net.FeedInput("data", img)
         net.Forward()
-        outs[level] = net.Extract("pw_odd_relu")
+        outs[level] = net.Extract("pw_seq_relu")
         if level == 2:
             fused = net.fused_pointwise()
-            names = [net.layers()[i][1] for i in fused]
-            assert names == ["dw0", "dw1", "dw2", "dw3", "dw4"], names
-            assert all(t != "Convolution" or not n.startswith("pw") for t, n, _ in net.layers())  # the pointwise layers were absorbed
+            names = [(net.layers()[i][1], one) for i, (_, one) in sorted(fused.items())]
+            # 32-, 16- and 8-pixel pairs run as one kernel; dw_odd (pad 0) is not even absorbed
+            assert names == [("dw0", True), ("dw1", True), ("dw3", True), ("dw4", True), ("dw_seq", False)], names  # dw2 (K = 64) is not absorbed
+            assert [n for t, n, _ in net.layers() if t == "Convolution"] == ["conv1", "pw2", "pw_odd"]  # every other pointwise layer was absorbed
     assert nerr(outs[2], outs[1]) <= 1e-5

@@ -11,7 +11,7 @@ A "step" is one forward pass of a benchmark network over one synthetic batch alr
       "nets" / "rooflines":  N = 1: ResNet-50 b64 (configs[2]), MobileNet-V1 b256 (configs[3]) and ResNet-50 with 512 images (the
       one-GPU point of configs[4]);  N > 1: configs[4] itself -- ResNet-50, 512 images in total sharded over the ranks (strong
       scaling) -- and its weak point (64 per GPU).
-  python bench.py --net resnet50|mobilenet_v1|vgg16|squeezenet_v1.1 [--batch B | --global-batch G] [--fusion 0|1|2]
+  python bench.py --net resnet50|mobilenet_v1|vgg16|squeezenet_v1.1 [--batch B | --global-batch G] [--fusion 0|1|2|3]
       Only that net (its images/s becomes `value`).
   python bench.py --mode convstack [--net ...]
       Only the convolution layers, each through ConvBooster::Forward with bias + ReLU fused and its input re-drawn (not chained).
@@ -63,7 +63,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="net mode: keep every layer on one stream (no branch concurrency)")
     ap.add_argument("--reference-selection", action="store_true",
                     help="route convolutions with the reference's SelectAlgo rule instead of the MI355X cost model (fhip_conv_select_algo_tuned)")
-    ap.add_argument("--fusion", type=int, default=2, help="net mode: 0 none, 1 the reference's TryFuse patterns, 2 also fold BN/Scale into conv weights")
+    ap.add_argument("--fusion", type=int, default=3, help="net mode: 0 none, 1 the reference's TryFuse patterns, 2 + BN/Scale folded into conv weights, "
+                    "conv+pool, conv+add, depthwise+pointwise, 3 + chained Winograd layers (feather_net.h, fhip_net_set_fusion)")
     return ap.parse_args()
 
 
@@ -239,6 +240,8 @@ def attribute(net, reps):
     info = net.layers()
     convs = net.conv_params()
     fused_pw = net.fused_pointwise()
+    chains = net.chains()
+    chain_bytes = 0.0
     fz_flops = fz_bytes = fz_ms = 0.0
     by_type, table = {}, []
     gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = direct = 0.0
@@ -274,7 +277,14 @@ def attribute(net, reps):
             elif a_id == WINOGRADF63:
                 tiles = ((p.output_h + 5) // 6) * ((p.output_w + 5) // 6)
                 gemm_flops += 2.0 * 64 * p.output_channels * p.input_channels * tiles * n
-                k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
+                v_in, v_out = chains.get(i, (False, False))
+                if not v_in:
+                    k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
+                else:
+                    chain_bytes += 4.0 * 64 * p.input_channels * tiles * n   # V' written by the chained transform of the layer before
+                if v_out:
+                    chain_bytes += 4.0 * 64 * p.output_channels * tiles * n  # M read by this layer's chained transform
+                    row["chained_to_next"] = True
             elif a_id == DEPTHWISE:
                 dw_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + p.output_channels * p.output_h * p.output_w) * n + 40.0 * p.input_channels
                 dw_ms += ms
@@ -309,6 +319,10 @@ def attribute(net, reps):
     if k2_bytes and stage.get("wino_input"):
         roofs.append(roofline_hbm("wino_input_transform_kernel", k2_bytes, stage["wino_input"], "4*(C*H*W + 64*C*T)*N summed over the Winograd "
                                   "layers / sum of the input-transform HIP-event durations"))
+    if chain_bytes and stage.get("wino_chain"):
+        roofs.append(roofline_hbm("wino_chain_kernel (output transform [+ max pooling] + next layer's input transform)", chain_bytes,
+                                  stage["wino_chain"], "4*64*(K*T + C'*T')*N -- M read, next layer's V written; the activation between the two layers "
+                                  "never exists -- summed over the chained layer boundaries / sum of their HIP-event durations"))
     return {"stage_ms_per_step": {k: round(v, 4) for k, v in stage.items()},
             "layer_type_ms_per_step": {k: round(v, 4) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1])},
             "rooflines": roofs, "conv_direct_flops_per_step": direct, "table": table}

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-STAGE_NAMES = ("wino_input", "wino_gemm", "wino_output", "igemm", "depthwise", "init")
+STAGE_NAMES = ("wino_input", "wino_gemm", "wino_output", "igemm", "depthwise", "init", "wino_chain")
 
 
 class fhip_conv_param(ctypes.Structure):
@@ -65,6 +65,9 @@ SIGNATURES = {
     "fhip_conv_forward_residual": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_dw_pw": (_I, [_P, _P, _I]),
     "fhip_conv_forward_dw_pw": (_I, [_P, _P, _I, _V, _V, _V, _V, _V, _V, _V]),
+    "fhip_conv_can_chain_winograd": (_I, [_P, _I, _P, _I, _I]),
+    "fhip_conv_forward_chained": (_I, [_P, _I, _V, _V, _V, _V, _V, _V, _P, _V, _I, _V]),
+    "fhip_winograd_f63_output_to_next_input": (_I, [_P, _P, _I, _V, _V, _V, _I, _V]),
     "fhip_conv_can_fuse_maxpool2": (_I, [_P, _I]),
     "fhip_conv_forward_maxpool2": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V]),
     "fhip_pooling_output_dim": (_I, [_Q, _PI, _PI]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "fhip_net_layer_info": (_I, [_V, _I, ctypes.c_char_p, ctypes.c_char_p, _I, _PI]),
     "fhip_net_layer_conv_param": (_I, [_V, _I, _P, _PI]),
     "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P, _PI]),
+    "fhip_net_layer_chain": (_I, [_V, _I, _PI, _PI]),
     "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
     "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }

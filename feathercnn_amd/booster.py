@@ -204,3 +204,36 @@ def winograd_plan(param: ConvParam):
     _check(_lib.load_library().fhip_winograd_f63_plan(ctypes.byref(c), max(param.batch, 1), ctypes.byref(pl)),
            "fhip_winograd_f63_plan")
     return pl
+
+
+def can_chain_winograd(a: "ConvLayer", b: "ConvLayer", pool: bool = False) -> bool:
+    ca, cb = a.param._c(), b.param._c()
+    return bool(_lib.load_library().fhip_conv_can_chain_winograd(ctypes.byref(ca), a.booster.algo, ctypes.byref(cb), b.booster.algo, int(pool)))
+
+
+def forward_chained(layers, x, pools=None):
+    """A run of Winograd ConvLayers through fhip_conv_forward_chained: the activations between them never exist (V ping-pongs
+    between two scratch buffers).  pools[i] = a 2x2 / stride-2 max pooling follows layer i.  Every adjacent pair must satisfy
+    can_chain_winograd.  -> output of the last layer (pooled if pools[-1])."""
+    import torch
+    lib = _lib.load_library()
+    pools = list(pools) if pools is not None else [False] * len(layers)
+    batch = x.shape[0]
+    plans = []
+    for l in layers:
+        l.param.batch = batch
+        plans.append(winograd_plan(l.param))
+    dev = x.device
+    vbuf = [torch.empty(max(pl.v_bytes for pl in plans[k::2]) // 4, dtype=torch.float32, device=dev) if plans[k::2] else None for k in (0, 1)]
+    m = torch.empty(max(pl.m_bytes for pl in plans) // 4, dtype=torch.float32, device=dev)
+    last = layers[-1].param
+    oh, ow = (last.output_h // 2, last.output_w // 2) if pools[-1] else (last.output_h, last.output_w)
+    out = torch.empty((batch, last.output_channels, oh, ow), dtype=torch.float32, device=dev)
+    for i, l in enumerate(layers):
+        c = l.param._c()
+        nxt = layers[i + 1].param._c() if i + 1 < len(layers) else None
+        _check(lib.fhip_conv_forward_chained(ctypes.byref(c), batch, _ptr(out) if nxt is None else None, _ptr(x) if i == 0 else None,
+                                             _ptr(l.packed), _ptr(vbuf[i & 1]), _ptr(m), _ptr(l.bias) if l.bias is not None else None,
+                                             ctypes.byref(nxt) if nxt is not None else None, _ptr(vbuf[(i + 1) & 1]) if nxt is not None else None,
+                                             int(pools[i]), _stream()), "fhip_conv_forward_chained")
+    return out

@@ -21,6 +21,9 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
 int winograd_output_transform(const fhip_conv_param& p, int batch, float* output, const float* m, const float* bias,
                               hipStream_t s, int pool = 0);
 bool winograd_can_pool(const fhip_conv_param& p);
+bool winograd_can_chain(const fhip_conv_param& p, const fhip_conv_param& next, int pool);
+int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_param& next, int batch, float* vn, const float* m, const float* bias,
+                                  hipStream_t s, int pool);
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
@@ -277,6 +280,32 @@ int fhip_conv_forward_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw
 {
     if (!valid_param(dw) || !valid_param(pw) || !output || !input || !dw_packed || !pw_packed || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
     return dwpw_forward(*dw, *pw, batch, output, input, dw_packed, dw_bias, pw_packed, pw_bias, (hipStream_t)stream);
+}
+
+int fhip_conv_can_chain_winograd(const fhip_conv_param* p, int algo, const fhip_conv_param* next, int next_algo, int pool)
+{
+    return valid_param(p) && valid_param(next) && algo == FHIP_WINOGRADF63 && next_algo == FHIP_WINOGRADF63 && winograd_can_chain(*p, *next, pool) ? 1 : 0;
+}
+
+int fhip_conv_forward_chained(const fhip_conv_param* p, int batch, float* output, const float* input, const float* packed, float* v, float* m,
+                              const float* bias, const fhip_conv_param* next, float* v_next, int pool, void* stream)
+{
+    if (!valid_param(p) || !packed || !v || !m || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
+    if (next ? (!valid_param(next) || !v_next) : !output) return fail(FHIP_E_BADARG, "a chained layer needs `next` and `v_next`, the last one `output`");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (input && (rc = winograd_input_transform(*p, batch, v, input, s))) return rc; // else V was written by the layer before
+    if ((rc = winograd_tile_gemm(*p, batch, m, packed, v, s))) return rc;
+    if (next) return winograd_output_to_next_input(*p, *next, batch, v_next, m, bias, s, pool);
+    if (pool && !winograd_can_pool(*p)) return fail(FHIP_E_UNSUPPORTED, "fused max pooling needs even output dims");
+    return winograd_output_transform(*p, batch, output, m, bias, s, pool);
+}
+
+int fhip_winograd_f63_output_to_next_input(const fhip_conv_param* p, const fhip_conv_param* next, int batch, float* v_next, const float* m,
+                                           const float* bias, int pool, void* stream)
+{
+    if (!valid_param(p) || !valid_param(next) || !v_next || !m || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
+    return winograd_output_to_next_input(*p, *next, batch, v_next, m, bias, (hipStream_t)stream, pool);
 }
 
 int fhip_winograd_f63_transform_kernel(const fhip_conv_param* p, float* u, const float* kernel, void* stream)

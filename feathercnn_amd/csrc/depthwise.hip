@@ -37,7 +37,7 @@ struct DwParams
 };
 
 constexpr int kDwChunkFloats = 3136;   // plane data per block of the small-plane 3x3 kernel
-constexpr int kDwChunkMaxPlane = 1024; // planes up to 32 x 32 go there (measured against the direct kernel: tools/dw_bench.hip)
+constexpr int kDwChunkMaxPlane = 256;  // stride-2 planes up to 16 x 16 go there -- the one case it beats the direct kernel (tools/dw_bench.hip)
 constexpr int kDwLdsFloats = 14336; // 56 KiB of plane data per block (+ weights) -> 2 blocks per CU (depthwise_lds_scalar_kernel)
 
 // Direct 3x3 form: no LDS, every lane produces a VX-wide x R-high output patch straight from global memory.
@@ -450,8 +450,9 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     const int HW = q.H * q.W;
     StageTimer tm(FHIP_STAGE_DEPTHWISE, s);
     const bool k3 = q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1;
-    // small planes (28 x 28 and below at MobileNet's shapes): the chunk-of-planes kernel; larger ones: the direct kernel
-    const bool small_plane = k3 && HW <= kDwChunkMaxPlane && q.OH * q.OW >= 1;
+    // small stride-2 planes (MobileNet's 14 x 14 -> 7 x 7, where a lane of the direct kernel has only 2 x 2 outputs to amortise its halo
+    // loads over): the chunk-of-planes kernel; everything else: the direct kernel
+    const bool small_plane = k3 && q.SH == 2 && HW <= kDwChunkMaxPlane;
     if (small_plane)
     {
         // ~3136 floats (12.25 KB) of planes per block: 4 x 28^2, 16 x 14^2, 64 x 7^2; a multiple of 4 planes keeps every chunk

@@ -245,6 +245,7 @@ struct Blob
     size_t capacity = 0;   // floats owned
     Blob* alias = nullptr; // data is another blob's
     bool fused_away = false;
+    bool chained = false; // fusion level 3: lives only as the next layer's Winograd-domain input (plan_chains); shape kept, no storage
 
     size_t count() const { return (size_t)n * c * h * w; }
     int reshape(int n_, int c_, int h_, int w_)
@@ -263,6 +264,12 @@ struct Blob
             capacity = count();
         }
         return 0;
+    }
+    void drop_storage()
+    {
+        if (data && capacity) (void)hipFree(data);
+        data = nullptr;
+        capacity = 0;
     }
     void share(Blob* src)
     {
@@ -341,6 +348,7 @@ struct Layer
     virtual int algo() const { return -1; }
     virtual const fhip_conv_param* conv_param() const { return nullptr; }
     virtual const fhip_conv_param* fused_pointwise(int*) const { return nullptr; } // the 1x1 convolution a depthwise layer absorbed
+    virtual void chain_state(int* v_from_previous, int* writes_next_v) const { *v_from_previous = *writes_next_v = 0; }
 };
 
 struct Net
@@ -357,6 +365,9 @@ struct Net
     bool tuned_selection = false; // fhip_conv_select_algo_tuned instead of the reference's SelectAlgo rule
     bool param_loaded = false, weights_loaded = false, fused = false, initialized = false, shapes_dirty = true;
     DeviceVec arena;
+    // fusion level 3 (plan_chains): runs of Winograd layers hand their transformed input from one to the next; the arena then holds two V
+    // slots (layers at even / odd positions of a run) and M
+    size_t chain_slot[2] = {0, 0}, chain_m = 0;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t owned_stream = nullptr; // graph capture is not allowed on the NULL stream
     // Branch concurrency (fhip_net_set_concurrency): a convolution that needs no scratch arena and whose output is consumed
@@ -416,6 +427,12 @@ struct ConvLayer : Layer
     std::unique_ptr<ConvLayer> pw;
     bool pair_fast = false;
     DeviceVec mid;
+    // fusion level 3 (plan_chains, after Reshape): this Winograd layer's input arrives already transformed (chain_in) and / or its
+    // output leaves as the next layer's transformed input (chain_next); chain_pos = position in the run (picks the V slot)
+    ConvLayer* chain_next = nullptr;
+    bool chain_in = false;
+    int chain_pos = 0;
+    size_t chain_bytes = 0; // arena the run needs (reported instead of buffer_bytes)
 
     ConvLayer()
     {
@@ -571,6 +588,20 @@ struct ConvLayer : Layer
             dwout.data = nullptr;
             return rc;
         }
+        if (chain_in || chain_next)
+        {
+            char* base = reinterpret_cast<char*>(net->arena.d);
+            float* v = reinterpret_cast<float*>(base + net->chain_slot[chain_pos & 1]);
+            float* vn = reinterpret_cast<float*>(base + net->chain_slot[(chain_pos + 1) & 1]);
+            float* m = reinterpret_cast<float*>(base + net->chain_m);
+            const float* in = chain_in ? nullptr : bottoms[0]->data;
+            const int n = bottoms[0]->n;
+            if (chain_next) return fhip_conv_forward_chained(&p, n, nullptr, in, packed.d, v, m, b, &chain_next->p, vn, fuse_pool ? 1 : 0, s);
+            if (!fuse_pool || pool_fast) return fhip_conv_forward_chained(&p, n, tops[0]->data, in, packed.d, v, m, b, nullptr, nullptr, fuse_pool ? 1 : 0, s);
+            const int rc = fhip_conv_forward_chained(&p, n, pre_pool.d, in, packed.d, v, m, b, nullptr, nullptr, 0, s);
+            if (rc) return rc;
+            return fhip_pooling(&poolq, n, tops[0]->data, pre_pool.d, s);
+        }
         if (residual)
         {
             if (residual->alias) residual->data = residual->alias->data;
@@ -605,9 +636,14 @@ struct ConvLayer : Layer
         if (one_kernel) *one_kernel = pair_fast ? 1 : 0;
         return pw ? &pw->p : nullptr;
     }
-    size_t arena_bytes() const override { return buffer_bytes; }
+    size_t arena_bytes() const override { return std::max(buffer_bytes, chain_bytes); }
     const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
+    void chain_state(int* v_from_previous, int* writes_next_v) const override
+    {
+        *v_from_previous = chain_in ? 1 : 0;
+        *writes_next_v = chain_next ? 1 : 0;
+    }
 };
 
 // feather::InnerProductLayer, layers/inner_product_layer.h:28-171: y = W x + b, W [out][in].  On the device it is a
@@ -1234,6 +1270,62 @@ static int plan_concurrency(Net& net)
     return 0;
 }
 
+// Fusion level 3, after Reshape (needs the routes and shapes): a Winograd layer directly followed by the 3x3 / stride-1 / pad-1 Winograd
+// layer that is the only consumer of its top hands over its output already transformed (fhip_conv_forward_chained); the blob between
+// them gets no storage.  VGG-16: conv1_2 ... conv5_3 become one run.
+static int plan_chains(Net& net)
+{
+    const size_t L = net.layers.size();
+    std::vector<ConvLayer*> conv(L, nullptr);
+    for (size_t i = 0; i < L; ++i)
+        if (net.layers[i]->type == "Convolution" || net.layers[i]->type == "ConvolutionDepthWise")
+        {
+            conv[i] = static_cast<ConvLayer*>(net.layers[i].get());
+            conv[i]->chain_next = nullptr;
+            conv[i]->chain_in = false;
+            conv[i]->chain_pos = 0;
+            conv[i]->chain_bytes = 0;
+        }
+    for (auto& kv : net.blobs) kv.second->chained = false;
+    net.chain_slot[0] = net.chain_slot[1] = net.chain_m = 0;
+    if (net.fusion < 3) return 0;
+    auto plain = [](const ConvLayer* c) { return c && !c->pw && !c->residual && c->algo_ == FHIP_WINOGRADF63 && c->tops.size() == 1 && c->bottoms.size() == 1; };
+    for (size_t i = 0; i + 1 < L; ++i)
+    {
+        ConvLayer *a = conv[i], *b = conv[i + 1];
+        if (!plain(a) || !plain(b) || b->bottoms[0] != a->tops[0]) continue;
+        if (a->fuse_pool && !a->pool_fast) continue;
+        int uses = 0;
+        for (size_t j = 0; j < L; ++j)
+            for (Blob* x : net.layers[j]->bottoms) uses += (x == a->tops[0] || x->alias == a->tops[0]) ? 1 : 0;
+        if (uses != 1) continue;
+        if (!fhip_conv_can_chain_winograd(&a->p, a->algo_, &b->p, b->algo_, a->fuse_pool ? 1 : 0)) continue;
+        a->chain_next = b;
+        b->chain_in = true;
+        b->chain_pos = a->chain_pos + 1;
+        a->tops[0]->chained = true;
+        a->tops[0]->drop_storage();
+    }
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t slot[2] = {0, 0}, msz = 0;
+    for (size_t i = 0; i < L; ++i)
+    {
+        ConvLayer* c = conv[i];
+        if (!c || (!c->chain_in && !c->chain_next)) continue;
+        fhip_winograd_plan pl;
+        const int rc = fhip_winograd_f63_plan(&c->p, c->bottoms[0]->n, &pl);
+        if (rc) return rc;
+        slot[c->chain_pos & 1] = std::max(slot[c->chain_pos & 1], up(pl.v_bytes));
+        msz = std::max(msz, up(pl.m_bytes));
+    }
+    net.chain_slot[0] = 0;
+    net.chain_slot[1] = slot[0];
+    net.chain_m = slot[0] + slot[1];
+    for (size_t i = 0; i < L; ++i)
+        if (conv[i] && (conv[i]->chain_in || conv[i]->chain_next)) conv[i]->chain_bytes = slot[0] + slot[1] + msz;
+    return 0;
+}
+
 static int reshape_all(Net& net)
 {
     net.drop_graph();
@@ -1242,8 +1334,12 @@ static int reshape_all(Net& net)
     {
         const int rc = l->Reshape();
         if (rc) return rc;
-        need = std::max(need, l->arena_bytes());
     }
+    {
+        const int rc = plan_chains(net);
+        if (rc) return rc;
+    }
+    for (auto& l : net.layers) need = std::max(need, l->arena_bytes());
     // one scratch arena shared by every layer = max over layers (mempool.cpp:88-92)
     if (need > net.arena.bytes)
     {
@@ -1478,6 +1574,8 @@ int fhip_net_extract(fhip_net* n, const char* blob_name, float** ptr, int* num, 
     Blob* b = n->impl.find(blob_name);
     if (!b) return failf(NET_E_IO, "Cannot find output blob %s", blob_name);
     if (b->fused_away) return failf(NET_E_IO, "blob %s was fused into its consumer; disable fusion to extract it", blob_name);
+    if (b->chained)
+        return failf(NET_E_IO, "blob %s exists only as the next layer's transformed input at fusion level 3; use level 2 to extract it", blob_name);
     if (b->alias) b->data = b->alias->data;
     *ptr = b->data;
     if (num) *num = b->n;
@@ -1537,6 +1635,14 @@ int fhip_net_layer_fused_pointwise(fhip_net* n, int index, fhip_conv_param* para
     const fhip_conv_param* cp = n->impl.layers[index]->fused_pointwise(one_kernel);
     if (!cp) return fail(FHIP_E_BADARG, "no pointwise convolution was absorbed into this layer");
     *param = *cp;
+    return FHIP_OK;
+}
+
+int fhip_net_layer_chain(fhip_net* n, int index, int* v_from_previous, int* writes_next_v)
+{
+    NET_GUARD(n);
+    if (index < 0 || index >= (int)n->impl.layers.size() || !v_from_previous || !writes_next_v) return fail(FHIP_E_BADARG, "layer index out of range");
+    n->impl.layers[index]->chain_state(v_from_previous, writes_next_v);
     return FHIP_OK;
 }
 

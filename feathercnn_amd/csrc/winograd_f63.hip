@@ -15,6 +15,8 @@
 // tile to one lane with lanes running along p, so all 64 V stores / M loads of a wave are 256-byte
 // coalesced rows, and the padding (pad_input) is folded into the input transform's bounds checks
 // instead of a padded copy of the input.
+#include <algorithm>
+
 #include "gemm_core.h"
 #include "wino_gemm_policy.h"
 #include "wino_gemm_glds.h"
@@ -351,6 +353,153 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K4 -> K2 chained: Y = A^T m A, + bias, ReLU [, 2x2 max pooling] of layer L, then V' = B^T d B of the 3x3 / stride-1 / pad-1 layer
+// that consumes it, WITHOUT the activation tensor in between: a block owns whole (image, channel) planes -- phase 1 transforms the
+// plane's M tiles and writes the activation into LDS (zero border = the consumer's padding, cells beyond the image zero), phase 2
+// reads the consumer's 8x8 windows from LDS and stores its V.  Same butterflies and the same fp32 values as K4 followed by K2, so
+// the chained V is bit-identical; what disappears is one write and one read of every activation between two Winograd layers
+// (VGG-16 b32: 1.47 GB of the 6.8 GB the transforms move per step) and one launch per layer.
+struct WinoChain
+{
+    int K, N;         // channels of the plane set (layer L's output = the consumer's input channels), images
+    int OH, OW;       // layer L's output image
+    int TX, T, Pp;    // layer L's tiling (M columns p = n*T + ty*TX + tx)
+    int AH, AW;       // activation the consumer sees: OH x OW, or OH/2 x OW/2 behind the fused pooling
+    int TX2, T2, Pp2; // the consumer's tiling / V' pitch
+    int planes;       // K * N, image index fastest: the planes of a block are consecutive images of one channel, whose tiles are
+                      // consecutive columns of M and V' (a 14 x 14 plane alone is 9 columns = 36 bytes of a row)
+    int ppb;          // planes per block
+    int LDW, LDH;     // LDS plane: (AH + 2 rows) x LDW floats, 2 border columns left, >= 2 right
+};
+
+template <bool HAS_BIAS, bool RELU, bool POOL>
+__global__ __launch_bounds__(512) void wino_chain_kernel(float* __restrict__ Vn, const float* __restrict__ M, const float* __restrict__ bias,
+                                                        const WinoChain g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[]; // [ppb][LDH][LDW]
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int plane0 = blockIdx.x * g.ppb;
+    const int np = min(g.ppb, g.planes - plane0);
+    const int plane_floats = g.LDH * g.LDW;
+    // Phase 1 writes rows 1 .. AH x columns 2 .. 2 + CW - 1 of every plane (CW = the columns layer L's tiles cover; cells beyond the image are
+    // written as zeros).  Everything else -- the consumer's padding and the slack its last tiles read -- is zeroed here; the two sets are
+    // disjoint, so there is no barrier in between and the M loads below are issued straight away.
+    {
+        const int right0 = 2 + (POOL ? 3 : 6) * g.TX, per_row = 2 + g.LDW - right0;
+        const int full_rows = g.LDH - g.AH; // row 0 and rows AH + 1 .. LDH - 1
+        for (int i = tid; i < np * full_rows * g.LDW; i += nthreads)
+        {
+            const int pl = i / (full_rows * g.LDW), r = i - pl * full_rows * g.LDW;
+            const int row = r / g.LDW, col = r - row * g.LDW;
+            smem[pl * plane_floats + (row == 0 ? 0 : g.AH + row) * g.LDW + col] = 0.f;
+        }
+        for (int i = tid; i < np * g.AH * per_row; i += nthreads)
+        {
+            const int pl = i / (g.AH * per_row), r = i - pl * g.AH * per_row;
+            const int y = r / per_row, e = r - y * per_row;
+            smem[pl * plane_floats + (y + 1) * g.LDW + (e < 2 ? e : right0 + e - 2)] = 0.f;
+        }
+    }
+
+    // ---- phase 1: layer L's tiles -> activation plane(s) in LDS
+    const size_t xi_stride = (size_t)g.K * g.Pp;
+    for (int w = tid; w < np * g.T; w += nthreads)
+    {
+        const int pl = w / g.T, t = w - pl * g.T;
+        const int plane = plane0 + pl;
+        const int k = plane / g.N, n = plane - k * g.N;
+        const int ty = t / g.TX, tx = t - ty * g.TX;
+        const float* mp = M + (size_t)k * g.Pp + (size_t)n * g.T + t;
+        float m[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[i][j] = mp[(size_t)(i * 8 + j) * xi_stride];
+        float tmp[6][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            at6(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], m[6][j], m[7][j], tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j], tmp[4][j], tmp[5][j]);
+        const float b = HAS_BIAS ? bias[k] : 0.f;
+        float* lp = smem + pl * plane_floats;
+        float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+        {
+            float y[6];
+            at6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], tmp[a][6], tmp[a][7], y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb)
+            {
+                float v = y[bb] + b;
+                if (RELU) v = fmaxf(v, 0.f);
+                y[bb] = v;
+            }
+            if (POOL)
+            {
+                // OH, OW even: a 2x2 cell never straddles the image edge; a whole cell is inside or outside
+                const float h0 = fmaxf(y[0], y[1]), h1 = fmaxf(y[2], y[3]), h2 = fmaxf(y[4], y[5]);
+                if ((a & 1) == 0)
+                {
+                    prev0 = h0;
+                    prev1 = h1;
+                    prev2 = h2;
+                }
+                else
+                {
+                    const int ay = 3 * ty + (a >> 1);
+                    if (ay < g.AH)
+                    {
+                        float* row = lp + (size_t)(ay + 1) * g.LDW + 2 + 3 * tx;
+                        row[0] = (3 * tx < g.AW) ? fmaxf(prev0, h0) : 0.f;
+                        row[1] = (3 * tx + 1 < g.AW) ? fmaxf(prev1, h1) : 0.f;
+                        row[2] = (3 * tx + 2 < g.AW) ? fmaxf(prev2, h2) : 0.f;
+                    }
+                }
+                continue;
+            }
+            const int ay = 6 * ty + a;
+            if (ay < g.AH)
+            {
+                float* row = lp + (size_t)(ay + 1) * g.LDW + 2 + 6 * tx; // even offset: 8-byte aligned pairs
+#pragma unroll
+                for (int bb = 0; bb < 6; bb += 2)
+                {
+                    const float v0 = (6 * tx + bb < g.AW) ? y[bb] : 0.f, v1 = (6 * tx + bb + 1 < g.AW) ? y[bb + 1] : 0.f;
+                    *reinterpret_cast<float2*>(row + bb) = make_float2(v0, v1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the consumer's tiles: window rows 6ty-1 .. 6ty+6, columns 6tx-1 .. 6tx+6 of the activation = LDS rows 6ty .. 6ty+7,
+    // columns 6tx+1 .. 6tx+8 (one border row on top, two border columns on the left)
+    const size_t xi_stride2 = (size_t)g.K * g.Pp2;
+    for (int w = tid; w < np * g.T2; w += nthreads)
+    {
+        const int pl = w / g.T2, t = w - pl * g.T2;
+        const int plane = plane0 + pl;
+        const int k = plane / g.N, n = plane - k * g.N;
+        const int ty = t / g.TX2, tx = t - ty * g.TX2;
+        const float* lp = smem + pl * plane_floats + (size_t)(6 * ty) * g.LDW + 6 * tx + 1;
+        float d[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[i][j] = lp[(size_t)i * g.LDW + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bt8(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
+        float* vp = Vn + (size_t)k * g.Pp2 + (size_t)n * g.T2 + t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * xi_stride2] = d[i][j];
+    }
+}
+
 // K3: the tile GEMM is gemm_core.h driven by WinoGemmPolicy (wino_gemm_policy.h)
 using WinoShapeBig = GemmShape<128, 64, 16, 2, 2>;     // K > 64: measured best on C >= 256 (73 % vs 70 %) and on small P
 using WinoShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
@@ -528,6 +677,81 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
         hipLaunchKernelGGL((wino_output_transform_kernel<false, true>), grid, dim3(256), 0, s, output, m, bias, q);
     else
         hipLaunchKernelGGL((wino_output_transform_kernel<false, false>), grid, dim3(256), 0, s, output, m, bias, q);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+// Chained output -> input transform.  `next` is the 3x3 / stride-1 / pad-1 Winograd layer that consumes layer p's output (after a
+// 2x2 / stride-2 max pooling when pool != 0); `vn` is ITS V buffer ([64][next.C][Pp2], winograd_plan(next, batch)).
+bool winograd_can_chain(const fhip_conv_param& p, const fhip_conv_param& next, int pool)
+{
+    if (p.kernel_h != 3 || p.kernel_w != 3 || p.stride_h > 1 || p.stride_w > 1 || p.group > 1) return false;
+    if (next.kernel_h != 3 || next.kernel_w != 3 || next.stride_h > 1 || next.stride_w > 1 || next.group > 1) return false;
+    if (next.pad_left != 1 || next.pad_right != 1 || next.pad_top != 1 || next.pad_bottom != 1) return false;
+    if (next.input_channels != p.output_channels) return false;
+    if (pool && ((p.output_h & 1) || (p.output_w & 1))) return false;
+    const int ah = pool ? p.output_h / 2 : p.output_h, aw = pool ? p.output_w / 2 : p.output_w;
+    if (next.input_h != ah || next.input_w != aw) return false;
+    // one plane of the activation (+ borders) must fit the LDS of a block: (ah + 2) x (6 * ceil((aw + 2 + 3) / 6) + 4) floats <= 64 KB
+    const int tx2 = (aw + 2 + 3) / 6, ty2 = (ah + 2 + 3) / 6;
+    return (size_t)(6 * ty2 + 2) * (6 * tx2 + 4) * sizeof(float) <= 64 * 1024;
+}
+
+int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_param& next, int batch, float* vn, const float* m, const float* bias,
+                                  hipStream_t s, int pool)
+{
+    if (!winograd_can_chain(p, next, pool)) return fail(FHIP_E_UNSUPPORTED, "these two layers cannot be chained (fhip_conv_can_chain_winograd)");
+    fhip_winograd_plan pl, pn;
+    int rc = winograd_plan(p, batch, &pl);
+    if (rc) return rc;
+    if ((rc = winograd_plan(next, batch, &pn))) return rc;
+    const bool has_bias = p.bias_term != 0, relu = p.activation == FHIP_ACT_RELU;
+    if (has_bias && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    WinoChain g;
+    g.K = p.output_channels;
+    g.N = batch;
+    g.OH = p.output_h;
+    g.OW = p.output_w;
+    g.TX = pl.tiles_x;
+    g.T = pl.tiles_per_image;
+    g.Pp = pl.columns_padded;
+    g.AH = next.input_h;
+    g.AW = next.input_w;
+    g.TX2 = pn.tiles_x;
+    g.T2 = pn.tiles_per_image;
+    g.Pp2 = pn.columns_padded;
+    const long long planes = (long long)batch * g.K;
+    if (planes > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N*K too large");
+    g.planes = (int)planes;
+    g.LDH = 6 * pn.tiles_y + 2;
+    g.LDW = 6 * pn.tiles_x + 4;
+    const size_t plane_bytes = (size_t)g.LDH * g.LDW * sizeof(float);
+    // one tile per lane: as many planes per block as 256 lanes and 48 KB of LDS (three blocks per CU) take; a plane of more than 256
+    // tiles (112 x 112: 361) gets a block of its own with a lane per tile
+    const int work = std::max(g.T, g.T2);
+    int ppb = std::max(1, 256 / work);
+    ppb = (int)std::min<size_t>(ppb, std::max<size_t>(1, (48 * 1024) / plane_bytes));
+    g.ppb = (int)std::min<long long>(ppb, planes);
+    const unsigned threads = work > 256 ? (unsigned)std::min(512, (work + 63) / 64 * 64) : 256u;
+    const size_t lds = plane_bytes * g.ppb;
+    const unsigned grid = (unsigned)((planes + g.ppb - 1) / g.ppb);
+    StageTimer tm(FHIP_STAGE_WINO_CHAIN, s);
+#define FHIP_CHAIN(B_, R_, P_) hipLaunchKernelGGL((wino_chain_kernel<B_, R_, P_>), dim3(grid), dim3(threads), lds, s, vn, m, bias, g)
+    if (pool)
+    {
+        if (has_bias && relu) FHIP_CHAIN(true, true, true);
+        else if (has_bias) FHIP_CHAIN(true, false, true);
+        else if (relu) FHIP_CHAIN(false, true, true);
+        else FHIP_CHAIN(false, false, true);
+    }
+    else
+    {
+        if (has_bias && relu) FHIP_CHAIN(true, true, false);
+        else if (has_bias) FHIP_CHAIN(true, false, false);
+        else if (relu) FHIP_CHAIN(false, true, false);
+        else FHIP_CHAIN(false, false, false);
+    }
+#undef FHIP_CHAIN
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }

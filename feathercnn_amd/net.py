@@ -132,6 +132,15 @@ class Net:
                 out[i] = (p, bool(one.value))
         return out
 
+    def chains(self):
+        """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3)."""
+        out = {}
+        for i in range(self._lib.fhip_net_layer_count(self._h)):
+            a, b = ctypes.c_int(), ctypes.c_int()
+            if self._lib.fhip_net_layer_chain(self._h, i, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value or b.value):
+                out[i] = (bool(a.value), bool(b.value))
+        return out
+
     def forward_timed(self):
         """One eager forward with HIP events around every layer: [(type, name, algo, ms)]."""
         n = self._lib.fhip_net_layer_count(self._h)

@@ -152,7 +152,7 @@ FHIP_API int fhip_winograd_f63_output_transform(const fhip_conv_param* param, in
 
 /* Stage timing with HIP events recorded on the launch stream (off by default; adds two event records per
  * kernel).  Stages: 0 winograd input transform, 1 tile GEMM, 2 winograd output transform,
- * 3 implicit-GEMM conv, 4 depthwise, 5 weight transforms. */
+ * 3 implicit-GEMM conv, 4 depthwise, 5 weight transforms, 6 chained Winograd output -> input transform. */
 enum fhip_stage
 {
     FHIP_STAGE_WINO_INPUT = 0,
@@ -161,7 +161,8 @@ enum fhip_stage
     FHIP_STAGE_IGEMM = 3,
     FHIP_STAGE_DEPTHWISE = 4,
     FHIP_STAGE_INIT = 5,
-    FHIP_STAGE_COUNT = 6
+    FHIP_STAGE_WINO_CHAIN = 6, /* chained output -> next layer's input transform (feather_net.h) */
+    FHIP_STAGE_COUNT = 7
 };
 FHIP_API int fhip_stage_timing_enable(int on);
 /* Synchronises the recorded events, adds their durations to per-stage totals, returns totals (ms) and

@@ -84,6 +84,27 @@ FHIP_API int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const f
  * `count_per_image` values of each image. */
 FHIP_API int fhip_softmax(float* y, const float* x, int batch, int count_per_image, void* stream);
 
+/* Consecutive Winograd layers without the activation between them.  When layer `p` (WINOGRADF63: 3x3, stride 1) is followed -- directly,
+ * or behind a 2x2 / stride-2 max pooling when pool = 1 -- by a 3x3 / stride-1 / pad-1 WINOGRADF63 layer `next` that is its only consumer,
+ * p's output transform can write next's TRANSFORMED INPUT V' (fhip_winograd_plan(next): [64][C'][P'_pad]) instead of the activation:
+ * one kernel does Y = A^T m A, + bias, ReLU [, pooling] into LDS (one whole (image, channel) plane per block, zero border = next's
+ * padding) and V' = B^T d B out of it, with the butterflies and the fp32 operation order of the two separate transforms, so V' is
+ * bit-identical.  The activation -- one HBM write and one read per layer boundary -- never exists (VGG-16: 11 of its 12 boundaries
+ * between 3x3 layers).  Equal to ConvLayer::Forward [+ PoolingLayer::Forward] of the reference followed by the input-transform step of
+ * the next ConvLayer::Forward (conv_layer.h:141-150; sgemm/winograd split: avx/booster.cpp:163-217, winograd_kernels_F63.cpp:64-515).
+ *   fhip_conv_can_chain_winograd: 1 when the pair qualifies (both WINOGRADF63, next 3x3/s1/p1 on exactly p's [pooled] output, the
+ *     padded plane fits a block's LDS: up to 112x112 activations).
+ *   fhip_conv_forward_chained runs ONE layer of such a run:  input != NULL -> first layer: transform `input` into `v` first;
+ *     input == NULL -> `v` already holds this layer's V (the previous call wrote it as its v_next).  next != NULL -> write next's V into
+ *     `v_next` (a different buffer than `v`; `output` is ignored); next == NULL -> last layer: write `output` (pooled when pool = 1,
+ *     as fhip_conv_forward_maxpool2).  `v` / `m` / `v_next` are caller-owned scratch of fhip_winograd_plan's v_bytes / m_bytes.
+ *   fhip_winograd_f63_output_to_next_input is the chained transform alone (stage-level tests and profiling). */
+FHIP_API int fhip_conv_can_chain_winograd(const fhip_conv_param* param, int algo, const fhip_conv_param* next, int next_algo, int pool);
+FHIP_API int fhip_conv_forward_chained(const fhip_conv_param* param, int batch, float* output, const float* input, const float* packed, float* v,
+                                       float* m, const float* bias, const fhip_conv_param* next, float* v_next, int pool, void* stream);
+FHIP_API int fhip_winograd_f63_output_to_next_input(const fhip_conv_param* param, const fhip_conv_param* next, int batch, float* v_next,
+                                                    const float* m, const float* bias, int pool, void* stream);
+
 /* ---- feather::Net on device blobs --------------------------------------------------------------------- */
 
 /* Opaque handle to a feather::Net (include/feather/net.h; reference net.h:30-70). */
@@ -93,8 +114,14 @@ FHIP_API int fhip_net_create(fhip_net** net);
 FHIP_API int fhip_net_destroy(fhip_net* net);
 /* All work of this net is enqueued on `stream` (default: the NULL stream).  Set before the first Forward. */
 FHIP_API int fhip_net_set_stream(fhip_net* net, void* stream);
-/* 1 (default): run the TryFuse pass the reference declares but never calls (layer.cpp:82-101):
- * Conv+ReLU, InnerProduct+ReLU, BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.  Set before LoadParam. */
+/* Fusion level.  Set before the first Forward.
+ *   0: none -- every layer of the file runs and every blob can be extracted, like the reference as shipped.
+ *   1 (default): the TryFuse pass the reference declares but never calls (layer.cpp:82-101): Conv+ReLU, InnerProduct+ReLU,
+ *      BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.
+ *   2: + BatchNorm / Scale folded into the convolution before them, Conv + 2x2 max pooling, Conv + Eltwise SUM (+ReLU), and a 3x3
+ *      depthwise layer + the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw where the pair qualifies).
+ *   3: + runs of Winograd layers chained (fhip_conv_forward_chained): the blob between two chained layers has a shape but no storage.
+ * A blob that a fusion removed cannot be extracted (fhip_net_extract fails and says which level to use). */
 FHIP_API int fhip_net_set_fusion(fhip_net* net, int on);
 /* 1: convolutions choose their route with fhip_conv_select_algo_tuned (MI355X cost model) instead of the reference's
  * SelectAlgo rule; 0 (default): the reference rule. */
@@ -142,6 +169,9 @@ FHIP_API int fhip_net_layer_conv_param(fhip_net* net, int index, fhip_conv_param
  * pair runs as one kernel at the current shape (fhip_conv_forward_dw_pw), 0 when it runs the two kernels one after the other.
  * FHIP_E_BADARG for every other layer. */
 FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_param* param, int* one_kernel);
+/* Fusion level 3: *v_from_previous = 1 when this convolution's transformed input is written by the layer before it (it runs no input
+ * transform), *writes_next_v = 1 when its output leaves as the next layer's transformed input (fhip_conv_forward_chained). */
+FHIP_API int fhip_net_layer_chain(fhip_net* net, int index, int* v_from_previous, int* writes_next_v);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

@@ -1,7 +1,7 @@
 """Oracle parity AT the BASELINE.json shapes: what bench.py times is what gets checked.
 
 (i)  The three metric nets at their bench configuration -- 224x224, the bench batch (VGG-16 32, ResNet-50 64,
-     MobileNet-V1 256), fusion level 2, MI355X conv routing, branch concurrency, hipGraph replay -- against the REAL reference
+     MobileNet-V1 256), fusion level 3, MI355X conv routing, branch concurrency, hipGraph replay -- against the REAL reference
      feather::Net (oracle/_ref, N = 1) on a few images of the batch (first, middle, last): logits and probabilities.
 (ii) One layer per route at the FULL benchmark batch with the real reference looped over the whole batch (no sampling):
      VGG conv1_2 / conv5_1 b32 (Winograd), ResNet-50 1x1 stride-1 / stride-2 b64 (implicit GEMM), MobileNet depthwise b256.
@@ -26,7 +26,7 @@ def test_bench_configuration_matches_reference_net(cuda, name, batch, logits):
     model = model_zoo.MODELS[name]()  # 224 x 224
     p, b, i, o = model
     x = np.random.default_rng(2024).uniform(-1, 1, (batch, 3, 224, 224)).astype(np.float32)
-    net = Net(fusion=2, graph=True, tuned=True, concurrency=True)  # exactly bench.py's setup_net
+    net = Net(fusion=3, graph=True, tuned=True, concurrency=True)  # exactly bench.py's setup_net
     net.LoadParam(p)
     net.LoadWeights(b)
     net.FeedInput(i, x)

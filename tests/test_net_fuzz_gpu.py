@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def random_net(seed):
+def random_net(seed, runs=False):
     rng = np.random.default_rng(seed)
     g = model_zoo.GraphBuilder(seed)
     c = int(rng.choice([3, 4, 8]))
@@ -50,8 +50,16 @@ def random_net(seed):
 
     c, h, w = shape
     for _ in range(int(rng.integers(3, 8))):
-        kind = rng.choice(["conv", "conv", "dw", "pool", "res", "fire", "drop"])
-        if kind == "conv":
+        kind = rng.choice(["conv", "conv", "dw", "pool", "res", "fire", "drop"] + (["run"] * 4 if runs else []))
+        if kind == "run" and min(h, w) >= 6:
+            # a VGG-style run: 3x3 / stride-1 / pad-1 layers, some behind a 2x2 / stride-2 max pooling (fusion level 3 chains these)
+            for _ in range(int(rng.integers(2, 5))):
+                x, c, h, w = conv(x, c, h, w, cout=int(rng.choice([4, 8, 12, 16])), k=3, s=1, p=1)
+                x = post(x, c)
+                if rng.random() < 0.35 and min(h, w) >= 8:
+                    x = g.pool(name("pool"), x, 2, 2, 0)
+                    h, w = -(-h // 2), -(-w // 2)
+        elif kind == "conv":
             x, c, h, w = conv(x, c, h, w)
             x = post(x, c)
         elif kind == "dw":
@@ -131,3 +139,44 @@ def test_random_topology(seed, cuda):
                 if m.any() and float(np.abs(ref[m]).max()) > 0:
                     assert float(np.abs(cur[m] - ref[m]).max()) <= TOL * float(np.abs(ref[m]).max()), (seed, name_)
         net.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_topology_with_winograd_runs_at_fusion_level_3(seed, cuda):
+    """Topologies rich in consecutive 3x3 layers: level 3 (chained Winograd layers, both routing rules) against the restatement and
+    bit for bit against level 2 under the same routing."""
+    from feathercnn_amd.net import Net
+    p, b, shape, out = random_net(5000 + seed, runs=True)
+    batch = 1 + seed % 3
+    img = np.random.default_rng(seed).uniform(-1, 1, (batch,) + shape).astype(np.float32)
+    want = netcheck.PortNet(p, b).run("data", img, out)
+    ok = ~np.isnan(want)
+    chained = 0
+    for tuned in (False, True):
+        outs = {}
+        for fusion in (2, 3):
+            net = Net(fusion=fusion, tuned=tuned, concurrency=tuned, graph=tuned and seed % 2 == 0)
+            net.LoadParam(p)
+            net.LoadWeights(b)
+            net.FeedInput("data", img)
+            for _ in range(3 if tuned else 1):
+                net.Forward()
+            outs[fusion] = net.Extract(out)
+            if fusion == 3:
+                chained += len(net.chains())
+            net.close()
+        assert np.array_equal(outs[2], outs[3], equal_nan=True), (seed, tuned)
+        assert np.array_equal(np.isnan(outs[3]), ~ok), (seed, tuned)
+        if ok.any() and float(np.abs(want[ok]).max()) > 0:
+            assert float(np.abs(outs[3][ok] - want[ok]).max()) <= TOL * float(np.abs(want[ok]).max()), (seed, tuned, p.decode())
+    _CHAINED.append(chained)
+
+
+_CHAINED = []
+
+
+def test_the_sweep_did_exercise_chains(cuda):
+    """Guard against the generator drifting: most of the 60 topologies above must have produced chained layers."""
+    if len(_CHAINED) < 60:
+        pytest.skip("runs only after the whole sweep")
+    assert sum(1 for c in _CHAINED if c > 0) >= 30, _CHAINED

@@ -43,6 +43,9 @@ PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 DEFAULT_BATCH = {"vgg16": 32, "resnet50": 64, "mobilenet_v1": 256, "squeezenet_v1.1": 64}
+# sub-batch replicas of the net per GPU (fhip_net_set_sub_batches), measured with tools/dual_stream_bench.py: MobileNet-V1 b256 gains 8 %
+# with two (its HBM-bound depthwise kernels run under the other share's MFMA-bound 1x1 kernels), VGG-16 and ResNet-50 gain nothing
+SUB_BATCHES = {"mobilenet_v1": 2}
 
 
 def parse():
@@ -63,6 +66,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="net mode: keep every layer on one stream (no branch concurrency)")
     ap.add_argument("--reference-selection", action="store_true",
                     help="route convolutions with the reference's SelectAlgo rule instead of the MI355X cost model (fhip_conv_select_algo_tuned)")
+    ap.add_argument("--sub-batches", type=int, default=0, help="replicas of the net on streams of their own, each taking a share of the batch "
+                    "(fhip_net_set_sub_batches); 0 = per-net default: 2 for mobilenet_v1 (HBM-bound depthwise under MFMA-bound 1x1 layers), else 1")
     ap.add_argument("--fusion", type=int, default=3, help="net mode: 0 none, 1 the reference's TryFuse patterns, 2 + BN/Scale folded into conv weights, "
                     "conv+pool, conv+add, depthwise+pointwise, 3 + chained Winograd layers (feather_net.h, fhip_net_set_fusion)")
     return ap.parse_args()
@@ -382,9 +387,16 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     nb = per_gpu_batch(net_name, a, env, global_batch, batch)
     model, t_bcast, bcast_bytes = broadcast_model(model_zoo.MODELS[net_name], dev, src=0)
     p, b, in_name, out_name = model
-    net = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection, concurrency=not a.no_overlap)
-    net.LoadParam(p)
-    net.LoadWeights(b)
+    replicas = a.sub_batches if a.sub_batches > 0 else SUB_BATCHES.get(net_name, 1)
+    replicas = max(1, min(replicas, nb))
+
+    def make_net(r):
+        n_ = Net(fusion=a.fusion, graph=not a.no_graph, tuned=not a.reference_selection, concurrency=not a.no_overlap, sub_batches=r)
+        n_.LoadParam(p)
+        n_.LoadWeights(b)
+        return n_
+
+    net = make_net(replicas)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     x = torch.rand((nb, 3, 224, 224), device=dev, generator=gen) * 2 - 1
@@ -397,12 +409,22 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     dt = timed_region(net.Forward, steps, warmup, env)
     total_images = global_batch if global_batch else world * nb
     res = {"net": net_name, "images_per_s": round(total_images * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-           "warmup": warmup, "per_gpu_batch": nb, "global_batch": total_images, "scaling": "strong" if global_batch else "weak"}
+           "warmup": warmup, "per_gpu_batch": nb, "global_batch": total_images, "scaling": "strong" if global_batch else "weak",
+           "sub_batches": replicas}
     if rank == 0 and detail:
+        if replicas > 1:
+            # kernels of concurrent replicas share the chip, so their individual durations are not a roofline measurement: the
+            # per-kernel attribution runs the same batch through a single-stream net (same kernels, same shapes but the batch)
+            net.close()
+            net = make_net(1)
+            net.FeedInput(in_name, x)
+            net.Forward()
+            torch.cuda.synchronize()
         att = attribute(net, max(3, min(steps, 5)))
         n_model_layers = len(netcheck_layers(p))
         res["workload"] = (f"{net_name} whole net ({n_model_layers} layers in the model file, {len(net.layers())} after fusion level {a.fusion}), "
-                           f"batch {nb} per GPU, 224x224x3, fp32, synthetic ncnn .param/.bin")
+                           f"batch {nb} per GPU" + (f" as {replicas} concurrent sub-batch replicas of the net (fhip_net_set_sub_batches)" if replicas > 1 else "")
+                           + ", 224x224x3, fp32, synthetic ncnn .param/.bin")
         res["conv_tflops_direct"] = round(att.pop("conv_direct_flops_per_step") * world / (dt / steps) / 1e12, 2)
         res.update(att)
         res["device_memory"] = net.memory()
@@ -624,10 +646,10 @@ def main():
         res["roofline"] = dom or (roofs[0] if roofs else head.get("roofline"))
         res["rooflines"] = {head_net: roofs}
         res["traffic_note"] = TRAFFIC_NOTE
-        nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling")}}
+        nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches")}}
         tables = {head_net: table}
         for name, e in extras.items():
-            nets_out[name] = {k: e[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "steps", "warmup") if k in e}
+            nets_out[name] = {k: e[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches", "steps", "warmup") if k in e}
             for k in ("workload", "stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "device_memory"):
                 if k in e:
                     nets_out[name][k] = e[k]

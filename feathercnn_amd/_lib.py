@@ -81,6 +81,7 @@ SIGNATURES = {
     "fhip_net_set_graph": (_I, [_V, _I]),
     "fhip_net_set_tuned_selection": (_I, [_V, _I]),
     "fhip_net_set_concurrency": (_I, [_V, _I]),
+    "fhip_net_set_sub_batches": (_I, [_V, _I]),
     "fhip_net_load_param": (_I, [_V, ctypes.c_char_p]),
     "fhip_net_load_param_mem": (_I, [_V, ctypes.c_char_p, _SZ]),
     "fhip_net_load_weights": (_I, [_V, ctypes.c_char_p]),

@@ -1440,8 +1440,31 @@ using namespace fhip::net;
 
 struct fhip_net
 {
-    Net impl;
+    Net impl; // the net -- or, with fhip_net_set_sub_batches(R > 1), the replica that takes the first share of every batch
+    // Sub-batch replicas: R - 1 further complete nets (own layers, weights, blobs, arena, stream, graph).  FeedInput deals the images
+    // out in contiguous shares, Forward runs all replicas concurrently (fork / join events against impl.stream), Extract puts the
+    // shares back together.  Images are independent, so no replica ever reads another's data.
+    std::vector<std::unique_ptr<fhip_net>> more;
+    std::vector<hipStream_t> more_streams;
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> joins;
+    std::vector<int> share;                    // images per replica at the last FeedInput (index 0 = impl)
+    std::map<std::string, DeviceVec> gathered; // Extract: blobs put back together (device pointer API)
+    ~fhip_net()
+    {
+        more.clear();
+        for (hipStream_t st : more_streams) (void)hipStreamDestroy(st);
+        if (fork) (void)hipEventDestroy(fork);
+        for (hipEvent_t e : joins) (void)hipEventDestroy(e);
+    }
 };
+
+// contiguous shares of `num` images for `parts` replicas, the remainder dealt to the first ones (feathercnn_amd/shard.py's rule)
+static void deal(int num, int parts, std::vector<int>& share)
+{
+    share.assign(parts, num / parts);
+    for (int r = 0; r < num % parts; ++r) ++share[r];
+}
 
 #define NET_GUARD(n) \
     if (!(n)) return fail(FHIP_E_BADARG, "null net")
@@ -1459,8 +1482,35 @@ int fhip_net_create(fhip_net** out)
 int fhip_net_destroy(fhip_net* n)
 {
     NET_GUARD(n);
+    for (auto& m : n->more)
+        if (m->impl.stream) (void)hipStreamSynchronize(m->impl.stream);
     if (n->impl.stream || n->impl.initialized) (void)hipStreamSynchronize(n->impl.stream);
     delete n;
+    return FHIP_OK;
+}
+
+int fhip_net_set_sub_batches(fhip_net* n, int replicas)
+{
+    NET_GUARD(n);
+    if (replicas < 1 || replicas > 16) return fail(FHIP_E_BADARG, "1 .. 16 sub-batches");
+    if (n->impl.param_loaded || !n->more.empty()) return fail(FHIP_E_BADARG, "set the number of sub-batches once, before LoadParam");
+    for (int r = 1; r < replicas; ++r)
+    {
+        hipStream_t st = nullptr;
+        FHIP_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        n->more_streams.push_back(st);
+        hipEvent_t e = nullptr;
+        FHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        n->joins.push_back(e);
+        std::unique_ptr<fhip_net> m(new fhip_net);
+        m->impl.stream = st;
+        m->impl.fusion = n->impl.fusion;
+        m->impl.use_graph = n->impl.use_graph;
+        m->impl.tuned_selection = n->impl.tuned_selection;
+        m->impl.concurrency = n->impl.concurrency;
+        n->more.push_back(std::move(m));
+    }
+    if (replicas > 1 && !n->fork) FHIP_CHECK_HIP(hipEventCreateWithFlags(&n->fork, hipEventDisableTiming));
     return FHIP_OK;
 }
 
@@ -1477,6 +1527,7 @@ int fhip_net_set_fusion(fhip_net* n, int on)
     NET_GUARD(n);
     if (n->impl.fused) return fail(FHIP_E_BADARG, "fusion already ran; set it before the first Forward");
     n->impl.fusion = on;
+    for (auto& m : n->more) m->impl.fusion = on;
     return FHIP_OK;
 }
 
@@ -1485,6 +1536,7 @@ int fhip_net_set_tuned_selection(fhip_net* n, int on)
     NET_GUARD(n);
     n->impl.tuned_selection = on != 0;
     n->impl.shapes_dirty = true;
+    for (auto& m : n->more) (void)fhip_net_set_tuned_selection(m.get(), on);
     return FHIP_OK;
 }
 
@@ -1493,6 +1545,7 @@ int fhip_net_set_concurrency(fhip_net* n, int on)
     NET_GUARD(n);
     n->impl.concurrency = on != 0;
     n->impl.shapes_dirty = true; // re-plan (and drop a captured graph) at the next Forward
+    for (auto& m : n->more) (void)fhip_net_set_concurrency(m.get(), on);
     return FHIP_OK;
 }
 
@@ -1506,6 +1559,7 @@ int fhip_net_set_graph(fhip_net* n, int on)
         if (!n->impl.owned_stream) FHIP_CHECK_HIP(hipStreamCreateWithFlags(&n->impl.owned_stream, hipStreamNonBlocking));
         n->impl.stream = n->impl.owned_stream;
     }
+    for (auto& m : n->more) (void)fhip_net_set_graph(m.get(), on); // the replicas already run on streams of their own
     return FHIP_OK;
 }
 
@@ -1513,6 +1567,11 @@ int fhip_net_load_param_mem(fhip_net* n, const char* text, size_t len)
 {
     NET_GUARD(n);
     if (!text) return fail(FHIP_E_BADARG, "null text");
+    for (auto& m : n->more)
+    {
+        const int rc = load_param_text(m->impl, text, len);
+        if (rc) return rc;
+    }
     return load_param_text(n->impl, text, len);
 }
 
@@ -1523,13 +1582,18 @@ int fhip_net_load_param(fhip_net* n, const char* path)
     std::vector<char> buf;
     const int rc = read_file(path, buf);
     if (rc) return rc;
-    return load_param_text(n->impl, buf.data(), buf.size());
+    return fhip_net_load_param_mem(n, buf.data(), buf.size());
 }
 
 int fhip_net_load_weights_mem(fhip_net* n, const void* data, size_t len)
 {
     NET_GUARD(n);
     if (!data && len) return fail(FHIP_E_BADARG, "null data");
+    for (auto& m : n->more)
+    {
+        const int rc = load_weights_mem(m->impl, data, len);
+        if (rc) return rc;
+    }
     return load_weights_mem(n->impl, data, len);
 }
 
@@ -1540,13 +1604,33 @@ int fhip_net_load_weights(fhip_net* n, const char* path)
     std::vector<char> buf;
     const int rc = read_file(path, buf);
     if (rc) return rc;
-    return load_weights_mem(n->impl, buf.data(), buf.size());
+    return fhip_net_load_weights_mem(n, buf.data(), buf.size());
 }
 
 int fhip_net_feed_input(fhip_net* n, const char* blob_name, int num, int c, int h, int w, const float* data, int on_device)
 {
     NET_GUARD(n);
     if (!blob_name || !data || num < 1 || c < 1 || h < 1 || w < 1) return fail(FHIP_E_BADARG, "bad argument");
+    if (!n->more.empty())
+    {
+        // deal the images out; a replica left without images (batch < replicas) sits the forward out
+        deal(num, (int)n->more.size() + 1, n->share);
+        if (on_device) FHIP_CHECK_HIP(hipEventRecord(n->fork, n->impl.stream)); // the caller's data is ordered on the net's stream
+        const size_t chw = (size_t)c * h * w;
+        size_t first = n->share[0];
+        for (size_t r = 0; r < n->more.size(); ++r)
+        {
+            const int cnt = n->share[r + 1];
+            if (cnt > 0)
+            {
+                if (on_device) FHIP_CHECK_HIP(hipStreamWaitEvent(n->more[r]->impl.stream, n->fork, 0));
+                const int rc = fhip_net_feed_input(n->more[r].get(), blob_name, cnt, c, h, w, data + first * chw, on_device);
+                if (rc) return rc;
+            }
+            first += cnt;
+        }
+        num = n->share[0];
+    }
     Blob* b = n->impl.find(blob_name);
     if (!b) return failf(NET_E_IO, "Invalid input blob %s, not found in map.", blob_name);
     if (b->n != num || b->c != c || b->h != h || b->w != w)
@@ -1564,7 +1648,25 @@ int fhip_net_feed_input(fhip_net* n, const char* blob_name, int num, int c, int 
 int fhip_net_forward(fhip_net* n)
 {
     NET_GUARD(n);
-    return forward(n->impl);
+    if (n->more.empty()) return forward(n->impl);
+    if (n->share.empty()) return failf(NET_E_SHAPE, "no input has been fed");
+    // fork: whatever the caller enqueued on the net's stream happens before every replica's forward; join: whatever the caller
+    // enqueues next (Extract, the next FeedInput) happens after all of them
+    FHIP_CHECK_HIP(hipEventRecord(n->fork, n->impl.stream));
+    for (size_t r = 0; r < n->more.size(); ++r)
+    {
+        if (n->share[r + 1] < 1) continue;
+        Net& m = n->more[r]->impl;
+        FHIP_CHECK_HIP(hipStreamWaitEvent(m.stream, n->fork, 0));
+        const int rc = forward(m);
+        if (rc) return rc;
+        FHIP_CHECK_HIP(hipEventRecord(n->joins[r], m.stream));
+    }
+    const int rc = forward(n->impl);
+    if (rc) return rc;
+    for (size_t r = 0; r < n->more.size(); ++r)
+        if (n->share[r + 1] > 0) FHIP_CHECK_HIP(hipStreamWaitEvent(n->impl.stream, n->joins[r], 0));
+    return FHIP_OK;
 }
 
 int fhip_net_extract(fhip_net* n, const char* blob_name, float** ptr, int* num, int* c, int* h, int* w)
@@ -1582,6 +1684,38 @@ int fhip_net_extract(fhip_net* n, const char* blob_name, float** ptr, int* num, 
     if (c) *c = b->c;
     if (h) *h = b->h;
     if (w) *w = b->w;
+    if (n->more.empty() || n->share.size() < 2 || n->share[1] < 1) return FHIP_OK;
+    // the blob lives in one piece per replica: put the pieces together (device-to-device, on the net's stream, after the join)
+    size_t total = b->count();
+    int images = b->n;
+    std::vector<std::pair<float*, size_t>> pieces(1, std::make_pair(b->data, b->count()));
+    for (size_t r = 0; r < n->more.size(); ++r)
+    {
+        if (n->share[r + 1] < 1) continue;
+        float* d = nullptr;
+        int pn, pc, ph, pw;
+        const int rc = fhip_net_extract(n->more[r].get(), blob_name, &d, &pn, &pc, &ph, &pw);
+        if (rc) return rc;
+        if (pc != b->c || ph != b->h || pw != b->w) return failf(NET_E_SHAPE, "blob %s has different shapes in the sub-batch replicas", blob_name);
+        pieces.push_back(std::make_pair(d, (size_t)pn * pc * ph * pw));
+        total += pieces.back().second;
+        images += pn;
+    }
+    DeviceVec& g = n->gathered[blob_name];
+    if (g.bytes < total * sizeof(float))
+    {
+        const int rc = g.resize(total * sizeof(float));
+        if (rc) return rc;
+    }
+    size_t at = 0;
+    for (auto& pc_ : pieces)
+    {
+        if (pc_.first && pc_.second)
+            FHIP_CHECK_HIP(hipMemcpyAsync(g.d + at, pc_.first, pc_.second * sizeof(float), hipMemcpyDeviceToDevice, n->impl.stream));
+        at += pc_.second;
+    }
+    *ptr = g.d;
+    if (num) *num = images;
     return FHIP_OK;
 }
 
@@ -1676,9 +1810,19 @@ int fhip_net_memory(fhip_net* n, size_t* blob_bytes, size_t* weight_bytes, size_
     for (auto& kv : n->impl.blobs) bb += kv.second->capacity * sizeof(float);
     for (auto& b : n->impl.shadowed) bb += b->capacity * sizeof(float);
     for (auto& l : n->impl.layers) wb += l->weight_bytes();
+    size_t ab = n->impl.arena.bytes;
+    for (auto& m : n->more)
+    {
+        size_t b2 = 0, w2 = 0, a2 = 0;
+        (void)fhip_net_memory(m.get(), &b2, &w2, &a2);
+        bb += b2;
+        wb += w2;
+        ab += a2;
+    }
+    for (auto& kv : n->gathered) bb += kv.second.bytes;
     if (blob_bytes) *blob_bytes = bb;
     if (weight_bytes) *weight_bytes = wb;
-    if (arena_bytes) *arena_bytes = n->impl.arena.bytes;
+    if (arena_bytes) *arena_bytes = ab;
     return FHIP_OK;
 }
 

@@ -12,7 +12,8 @@ from .booster import ALGO_NAMES, FeatherHipError, _check, _stream
 
 
 class Net:
-    def __init__(self, fusion: int = 1, graph: bool = False, stream=None, tuned: bool = False, concurrency: bool = False):
+    def __init__(self, fusion: int = 1, graph: bool = False, stream=None, tuned: bool = False, concurrency: bool = False,
+                 sub_batches: int = 1):
         self._lib = _lib.load_library()
         h = ctypes.c_void_p()
         _check(self._lib.fhip_net_create(ctypes.byref(h)), "fhip_net_create")
@@ -23,6 +24,8 @@ class Net:
         _check(self._lib.fhip_net_set_concurrency(h, int(bool(concurrency))), "fhip_net_set_concurrency")
         if stream is not None:
             _check(self._lib.fhip_net_set_stream(h, ctypes.c_void_p(stream)), "fhip_net_set_stream")
+        if sub_batches != 1:  # replicas of the net on streams of their own, each taking a share of every batch (feather_net.h)
+            _check(self._lib.fhip_net_set_sub_batches(h, int(sub_batches)), "fhip_net_set_sub_batches")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -75,8 +78,7 @@ class Net:
             raise FeatherHipError("FeedInput wants [N][C][H][W] or [C][H][W]")
         n, c, h, w = (int(v) for v in shape)
         _check(self._lib.fhip_net_feed_input(self._h, input_name.encode(), n, c, h, w, ptr, dev), "fhip_net_feed_input")
-        if not dev:
-            self.synchronize()  # the host array may be freed by the caller
+        self.synchronize()  # the host array / device tensor may be freed or overwritten by the caller
         del keep
         return 0
 

@@ -106,6 +106,7 @@ class Net
     int SetGraph(bool on) { return fhip_net_set_graph(net_, on ? 1 : 0); }
     int SetTunedSelection(bool on) { return fhip_net_set_tuned_selection(net_, on ? 1 : 0); }
     int SetConcurrency(bool on) { return fhip_net_set_concurrency(net_, on ? 1 : 0); }
+    int SetSubBatches(int replicas) { return fhip_net_set_sub_batches(net_, replicas); } // before LoadParam (feather_net.h)
     int LayerCount() { return fhip_net_layer_count(net_); }
     static const char* LastError() { return fhip_last_error(); }
     fhip_net* handle() { return net_; }

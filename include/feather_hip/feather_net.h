@@ -135,6 +135,16 @@ FHIP_API int fhip_net_set_concurrency(fhip_net* net, int on);
  * inputs produced on other streams yourself). */
 FHIP_API int fhip_net_set_graph(fhip_net* net, int on);
 
+/* Sub-batch replicas (default 1 = off).  With R > 1 the handle owns R complete copies of the net (weights, blobs, arena, graph), each on a
+ * stream of its own: FeedInput deals the images of a batch out in R contiguous shares (the first ones take the remainder), Forward
+ * runs the replicas concurrently -- forked off and joined back into the net's stream with events, so the caller's stream order is
+ * unchanged -- and Extract puts the shares back together ([N][C][H][W], images in feed order).  Images are independent, so results
+ * equal the single-net ones up to the batch-dependent reduction order of split-K layers (<= 1e-6 normalised).  What it buys: kernels of
+ * different character overlap (MobileNet-V1 b256: HBM-bound depthwise layers of one share under the MFMA-bound 1x1 layers of the
+ * other, +8 % images/s with R = 2) and the tails of small launches are filled; nets made of long uniform launches gain nothing
+ * (VGG-16, ResNet-50: +-1 %).  Set once, before LoadParam.  Introspection calls and fhip_net_forward_timed describe replica 0. */
+FHIP_API int fhip_net_set_sub_batches(fhip_net* net, int replicas);
+
 /* Net::LoadParam, net.cpp:54-170 (ncnn text .param: magic 7767517, "layers blobs", one line per layer). */
 FHIP_API int fhip_net_load_param(fhip_net* net, const char* path);
 FHIP_API int fhip_net_load_param_mem(fhip_net* net, const char* text, size_t len);

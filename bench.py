@@ -249,7 +249,7 @@ def attribute(net, reps):
     chain_bytes = 0.0
     fz_flops = fz_bytes = fz_ms = 0.0
     by_type, table = {}, []
-    gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = direct = 0.0
+    gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = pw_bound_ms = direct = 0.0
     pw_rows = []
     for i, ((typ, nm, algo), ms) in enumerate(zip(info, per_layer)):
         key = typ + ("/" + algo if algo else "")
@@ -298,6 +298,13 @@ def attribute(net, reps):
                 pw_ms += ms
                 row["mfma_frac"] = round(fl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)
                 pw_rows.append(row["mfma_frac"])
+                # the layer's own lower bound: its matrix work at the MFMA peak or its compulsory bytes (the pixels the stride keeps, the
+                # output, the weights; a fused residual operand is NOT counted) at the HBM peak, whichever is longer
+                by = 4.0 * ((p.input_channels + p.output_channels) * p.output_h * p.output_w * n + p.input_channels * p.output_channels)
+                t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e9), by / (PEAK_HBM_GBS * 1e6)
+                pw_bound_ms += max(t_mfma, t_hbm)
+                row["bound"] = "hbm" if t_hbm > t_mfma else "mfma"
+                row["bound_frac"] = round(max(t_mfma, t_hbm) / max(ms, 1e-9), 4)
         table.append(row)
     roofs = []
     if gemm_flops and stage.get("wino_gemm"):
@@ -311,6 +318,9 @@ def attribute(net, reps):
         r["layers"] = len(pw_rows)
         r["layer_frac_min"] = min(pw_rows)
         r["layer_frac_mean"] = round(sum(pw_rows) / len(pw_rows), 4)
+        # sum of the layers' own lower bounds (max of MFMA time at 157.3 TF and HBM time at 8 TB/s, per layer) / measured time: what the
+        # MFMA fraction alone understates for the layers that are bandwidth-bound at this batch (ResNet-50's 64 -> 256 @56x56)
+        r["frac_of_tighter_bound"] = round(pw_bound_ms / pw_ms, 4)
         roofs.append(r)
     if dw_bytes and stage.get("depthwise"):
         roofs.append(roofline_hbm("depthwise3x3_direct_kernel", dw_bytes, stage["depthwise"], "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C "

@@ -206,10 +206,33 @@ def net_cpu_baseline(net_name, model, procs):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+_SUSTAINED = {}
+
+
+def sustained_mfma():
+    """fhip_calibrate_mfma_f32, once per process: what a kernel made of nothing but fp32 MFMAs reaches on THIS device (the chip clocks
+    to its power budget under full-chip matrix load), and the shader clock it ran at."""
+    if not _SUSTAINED:
+        from feathercnn_amd import booster
+        try:
+            tf, mhz = booster.calibrate_mfma_f32()
+            _SUSTAINED.update({"tflops": round(tf, 1), "shader_mhz": round(mhz)})
+        except Exception as e:  # a measurement aid must never take the benchmark down
+            _SUSTAINED.update({"tflops": None, "error": repr(e)})
+    return _SUSTAINED
+
+
 def roofline_mfma(kernel, flops, ms, note):
     ach = flops / ms / 1e9
-    return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None, "work_per_step": flops, "ms_per_step": round(ms, 4), "note": note}
+    r = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None, "work_per_step": flops, "ms_per_step": round(ms, 4), "note": note}
+    sus = sustained_mfma()
+    if sus.get("tflops"):
+        # next to the nominal peak (2.4 GHz): the measured ceiling of a pure-MFMA kernel on this device in this process
+        r["sustained_peak_measured"] = sus["tflops"]
+        r["shader_mhz_under_mfma_load"] = sus["shader_mhz"]
+        r["frac_of_sustained"] = round(ach / sus["tflops"], 4)
+    return r
 
 
 def roofline_hbm(kernel, nbytes, ms, note):
@@ -656,6 +679,8 @@ def main():
         res["roofline"] = dom or (roofs[0] if roofs else head.get("roofline"))
         res["rooflines"] = {head_net: roofs}
         res["traffic_note"] = TRAFFIC_NOTE
+        res["mfma_calibration"] = dict(sustained_mfma(), note="fhip_calibrate_mfma_f32: a kernel of nothing but v_mfma_f32_32x32x2_f32 chains at 3 "
+                                       "waves per SIMD on every CU; its TFLOP/s and the shader clock it ran at (nominal peak 157.3 TFLOP/s assumes 2.4 GHz)")
         nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches")}}
         tables = {head_net: table}
         for name, e in extras.items():

@@ -237,3 +237,10 @@ def forward_chained(layers, x, pools=None):
                                              ctypes.byref(nxt) if nxt is not None else None, _ptr(vbuf[(i + 1) & 1]) if nxt is not None else None,
                                              int(pools[i]), _stream()), "fhip_conv_forward_chained")
     return out
+
+
+def calibrate_mfma_f32():
+    """-> (TFLOP/s the fp32 matrix pipe of this device sustains under full-chip load, shader clock in MHz it ran at) -- feather_hip.h."""
+    tf, mhz = ctypes.c_double(), ctypes.c_double()
+    _check(_lib.load_library().fhip_calibrate_mfma_f32(ctypes.byref(tf), ctypes.byref(mhz), _stream()), "fhip_calibrate_mfma_f32")
+    return tf.value, mhz.value

@@ -389,4 +389,114 @@ int fhip_device_info(char* name, int name_len, int* cus, int* lds_bytes)
     return FHIP_OK;
 }
 
+// ---- calibration: what the fp32 matrix pipe sustains on THIS device, at the clock the chip really runs it at -------------------
+namespace
+{
+typedef float cal_f32x16 __attribute__((ext_vector_type(16)));
+__device__ unsigned long long g_cal_ticks[2]; // shader-clock ticks, 100 MHz wall-clock ticks (sampled blocks)
+
+// Nothing but v_mfma_f32_32x32x2_f32: four independent accumulator chains per wave, 3 waves per SIMD (the residency of the product's
+// GEMM kernels), operands in registers.  Whatever this kernel reaches is the ceiling every MFMA-bound kernel of the library lives under.
+// The operands are eight random values per lane that rotate from MFMA to MFMA: dynamic power follows the toggling of the operand
+// bits, constant operands run 10 % faster than anything a real GEMM can reach on this part.
+__global__ __launch_bounds__(256) void mfma_calibration_kernel(float* sink, const float* noise, int steps)
+{
+    const long long c0 = clock64(), w0 = wall_clock64();
+    cal_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+    {
+        a[u] = noise[(threadIdx.x * 16 + u + blockIdx.x) & 4095];
+        b[u] = noise[(threadIdx.x * 16 + 8 + u + 3 * blockIdx.x) & 4095];
+    }
+    for (int s = 0; s < steps; ++s)
+    {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + 3) & 7], b[(u + 5) & 7], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + 1) & 7], b[(u + 2) & 7], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + 6) & 7], b[(u + 7) & 7], acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(a[u]), "+v"(b[u]));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[t][r];
+    if (sum == 123.456f) sink[0] = sum; // keeps the chains alive
+    if (threadIdx.x == 0 && (blockIdx.x & 15) == 0)
+    {
+        atomicAdd(&g_cal_ticks[0], (unsigned long long)(clock64() - c0));
+        atomicAdd(&g_cal_ticks[1], (unsigned long long)(wall_clock64() - w0));
+    }
+}
+} // namespace
+
+int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream)
+{
+    if (!tflops || !shader_mhz) return fail(FHIP_E_BADARG, "null argument");
+    int dev = 0;
+    FHIP_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FHIP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = prop.multiProcessorCount * 3, steps = 256; // 3 blocks of 4 waves per CU, 8192 MFMAs per wave: ~0.8 ms
+    float *sink = nullptr, *noise = nullptr;
+    FHIP_CHECK_HIP(hipMalloc((void**)&sink, 4));
+    FHIP_CHECK_HIP(hipMalloc((void**)&noise, 4096 * sizeof(float)));
+    {
+        std::vector<float> h(4096);
+        unsigned x = 2463534242u;
+        for (auto& v : h)
+        {
+            x ^= x << 13;
+            x ^= x >> 17;
+            x ^= x << 5;
+            v = (float)(int)x * (1.0f / 2147483648.0f); // U(-1, 1): what the nets' activations and weights look like
+        }
+        FHIP_CHECK_HIP(hipMemcpyAsync(noise, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        FHIP_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    hipEvent_t e0, e1;
+    FHIP_CHECK_HIP(hipEventCreate(&e0));
+    FHIP_CHECK_HIP(hipEventCreate(&e1));
+    const unsigned long long zero[2] = {0, 0};
+    double best_tf = 0, best_mhz = 0;
+    for (int rep = 0; rep < 12; ++rep) // the first repetition warms up; the power manager takes a few ms to settle: best of the rest
+    {
+        FHIP_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cal_ticks), zero, sizeof zero, 0, hipMemcpyHostToDevice, s));
+        FHIP_CHECK_HIP(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(mfma_calibration_kernel, dim3(blocks), dim3(256), 0, s, sink, noise, steps);
+        FHIP_CHECK_HIP(hipEventRecord(e1, s));
+        FHIP_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        FHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long ticks[2] = {0, 0};
+        FHIP_CHECK_HIP(hipMemcpyFromSymbol(ticks, HIP_SYMBOL(g_cal_ticks), sizeof ticks));
+        const double flops = 2.0 * 32 * 32 * 2 * 32.0 * steps * 4.0 * blocks; // per MFMA x 32 MFMAs per step x waves
+        const double tf = flops / (ms * 1e-3) / 1e12, mhz = ticks[1] ? (double)ticks[0] / (double)ticks[1] * 100.0 : 0.0;
+        if (rep > 0 && tf > best_tf)
+        {
+            best_tf = tf;
+            best_mhz = mhz;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(noise);
+    *tflops = best_tf;
+    *shader_mhz = best_mhz;
+    return FHIP_OK;
+}
+
 } // extern "C"

@@ -188,4 +188,126 @@ __global__ __launch_bounds__(64 * WAVES) void stream_pw_kernel(const StreamParam
         }
     }
 }
+
+// ---- split-C variant: the WAVES = 4 waves of a block split the input channels of (4 / SPLIT) m-groups of one pixel tile between them
+// (SPLIT = 2 or 4) and add their accumulators through LDS in a fixed order.  Four (two) times as many, four (two) times shorter waves:
+// the last partial round of the grid -- the waves that run while most SIMDs are already idle -- shrinks accordingly.
+template <int D, int SPLIT, int ABL = 0>
+__global__ __launch_bounds__(256) void stream_pw_split_kernel(const StreamParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[]; // [slot][16 regs x 4][64 lanes] float4-interleaved
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int MGB = 4 / SPLIT; // m-groups per block
+    const int mg_blocks = q.mgroups / MGB;
+    int vid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qx = nwg / 8, rx = nwg % 8, xcd = vid % 8, local = vid / 8;
+        vid = ((xcd < rx) ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + local;
+    }
+    const int pt = vid / mg_blocks, mg = (vid - pt * mg_blocks) * MGB + wave / SPLIT, cp = wave % SPLIT;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long long g = (long long)pt * 128 + 4 * l31;
+    const bool ok = g < q.total_px;
+    const long long gc = ok ? g : 0;
+    const int n = (int)(gc / q.HW), p = (int)(gc - (long long)n * q.HW);
+    const int J = q.C / 2 / SPLIT; // steps of this wave: channels [cp * C / SPLIT, (cp + 1) * C / SPLIT); a multiple of D
+    const float* bp = q.in + ((size_t)n * q.C + half + (size_t)cp * 2 * J) * q.HW + p;
+    const float* ap = q.wp + ((size_t)mg * (q.C / 2) + (size_t)cp * J) * 64 + lane;
+    const size_t bstep = (size_t)2 * q.HW;
+
+    f32x16s acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4s b[D];
+    float a[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+    {
+        STREAM_LD4(b[u], bp + (size_t)u * bstep);
+        STREAM_LD1(a[u], ap + (size_t)u * 64);
+    }
+    const float* bnext = bp + (size_t)D * bstep;
+    const float* anext = ap + (size_t)D * 64;
+    for (int j0 = 0; j0 < J - D; j0 += D)
+    {
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+        {
+            STREAM_WAIT(2 * D - 2, b[u], a[u]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].w, acc[3], 0, 0, 0);
+            STREAM_LD4(b[u], bnext + (size_t)u * bstep);
+            STREAM_LD1(a[u], anext + (size_t)u * 64);
+        }
+        bnext += (size_t)D * bstep;
+        anext += (size_t)D * 64;
+    }
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+    {
+        STREAM_WAIT(2 * (D - u) - 2, b[u], a[u]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].w, acc[3], 0, 0, 0);
+    }
+    // ---- fixed-order reduction: (c0 + c2) + (c1 + c3) for SPLIT = 4, c0 + c1 for SPLIT = 2.  A slot = one wave's 64 accumulator
+    // registers as 16 float4 per lane ([reg][lane] float4: conflict-free 16-byte accesses)
+    constexpr int SLOT = 16 * 64 * 4;
+    float4* const slots = reinterpret_cast<float4*>(red);
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slots[(slot * 16 + r) * 64 + lane] = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            const float4 v = slots[(slot * 16 + r) * 64 + lane];
+            acc[0][r] += v.x;
+            acc[1][r] += v.y;
+            acc[2][r] += v.z;
+            acc[3][r] += v.w;
+        }
+    };
+    (void)SLOT;
+    const int grp = wave / SPLIT; // m-group of the block this wave works for
+    if (SPLIT == 4)
+    {
+        if (cp >= 2) put(cp - 2);
+        __syncthreads();
+        if (cp < 2) add(cp);
+        if (cp == 1) put(2);
+        __syncthreads();
+        if (cp == 0) add(2);
+    }
+    else
+    {
+        if (cp == 1) put(grp);
+        __syncthreads();
+        if (cp == 0) add(grp);
+    }
+    if (cp != 0 || !ok) return;
+    float* op = q.out + ((size_t)n * q.K + 32 * mg + 4 * half) * q.HW + p;
+    const float* bsp = q.bias + 32 * mg + 4 * half;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const float bs = bsp[row];
+        float4 v = make_float4(acc[0][r] + bs, acc[1][r] + bs, acc[2][r] + bs, acc[3][r] + bs);
+        if (q.relu)
+        {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(op + (size_t)row * q.HW) = v;
+    }
+}
 } // namespace fhip

@@ -67,6 +67,14 @@ static void launch_stream(const StreamParams& q)
     hipLaunchKernelGGL((stream_pw_kernel<D, WAVES, MG, XCD, ABL>), dim3((unsigned)(q.px_tiles * mg_blocks)), dim3(64 * WAVES), 0, 0, q);
 }
 
+template <int D, int SPLIT>
+static void launch_split(const StreamParams& q)
+{
+    const int mg_blocks = q.mgroups / (4 / SPLIT);
+    const size_t lds = (SPLIT == 4 ? 3 : 2) * 16 * 64 * 16;
+    hipLaunchKernelGGL((stream_pw_split_kernel<D, SPLIT>), dim3((unsigned)(q.px_tiles * mg_blocks)), dim3(256), lds, 0, q);
+}
+
 static void run(const Case& cs)
 {
     if ((cs.H * cs.H) % 4) return; // the experiment needs 16-byte aligned pixel groups inside one image
@@ -120,9 +128,10 @@ static void run(const Case& cs)
     vars.push_back({"product (C-ABI)", [&] { CF(fhip_conv_forward(&p, FHIP_IM2COL, cs.N, out_ref, in, packed, buf, bias, nullptr)); }});
     vars.push_back({"stream D8 w4", [&] { launch_stream<8, 4, 1>(q); }});
     vars.push_back({"stream D16 w4", [&] { launch_stream<16, 4, 1>(q); }});
-    vars.push_back({"D8 w4 no loads", [&] { launch_stream<8, 4, 1, true, 1>(q); }});
-    vars.push_back({"D8 w4 no stores", [&] { launch_stream<8, 4, 1, true, 2>(q); }});
-    vars.push_back({"D8 w4 MFMA only", [&] { launch_stream<8, 4, 1, true, 3>(q); }});
+    if (cs.C >= 32) vars.push_back({"split2 D8", [&] { launch_split<8, 2>(q); }});
+    if (cs.C >= 64) vars.push_back({"split4 D8", [&] { launch_split<8, 4>(q); }});
+    if (cs.C >= 128) vars.push_back({"split4 D16", [&] { launch_split<16, 4>(q); }});
+    if (cs.C >= 64) vars.push_back({"split2 D16", [&] { launch_split<16, 2>(q); }});
     std::vector<std::vector<double>> ms(vars.size());
     for (int round = 0; round < 3; ++round)
         for (size_t v = 0; v < vars.size(); ++v)

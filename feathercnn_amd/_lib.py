@@ -57,6 +57,7 @@ SIGNATURES = {
     "fhip_last_error": (ctypes.c_char_p, []),
     "fhip_version": (ctypes.c_char_p, []),
     "fhip_device_info": (_I, [ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "fhip_conv_streams_1x1": (_I, [_P, _I, _I]),
     "fhip_calibrate_mfma_f32": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _V]),
     # include/feather_hip/feather_net.h -- layers between the convolutions
     "fhip_relu": (_I, [_V, _V, _SZ, _V]),

@@ -29,6 +29,8 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
 int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* packed, const float* bias,
                   float* buffer, bool force_no_act, hipStream_t s, const float* residual = nullptr);
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch);
+size_t igemm_packed_floats(const fhip_conv_param& p);
+bool igemm_streams(const fhip_conv_param& p, int batch);
 int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const float* in, const float* kernel, const float* bias,
                       hipStream_t s);
 int depthwise_init(const fhip_conv_param& p, float* packed, const float* kernel, hipStream_t s);
@@ -177,10 +179,8 @@ int fhip_conv_get_buffer_size(const fhip_conv_param* p, int algo, int batch, siz
         case FHIP_IM2COL:
         {
             if (p->group > 1) return fail(FHIP_E_UNSUPPORTED, "implicit GEMM handles group == 1 only");
-            int kdp, kp;
-            igemm_packed_dims(*p, &kdp, &kp);
             *buffer_bytes = igemm_buffer_bytes(*p, batch); // no column matrix; split-K partial sums for under-filled grids only
-            *packed_bytes = (size_t)kdp * kp * sizeof(float);
+            *packed_bytes = igemm_packed_floats(*p) * sizeof(float);
             return FHIP_OK;
         }
         case FHIP_DEPTHWISE:
@@ -261,6 +261,11 @@ int fhip_conv_forward_residual(const fhip_conv_param* p, int algo, int batch, fl
 {
     if (!residual) return fail(FHIP_E_BADARG, "null residual");
     return conv_forward_impl(p, algo, batch, output, input, packed, buffer, bias, stream, 0, residual);
+}
+
+int fhip_conv_streams_1x1(const fhip_conv_param* p, int algo, int batch)
+{
+    return valid_param(p) && (algo == FHIP_IM2COL || algo == FHIP_NAIVE) && batch >= 1 && igemm_streams(*p, batch) ? 1 : 0;
 }
 
 int fhip_conv_can_fuse_residual(const fhip_conv_param* p, int algo) { return valid_param(p) && algo == FHIP_IM2COL ? 1 : 0; }

@@ -14,6 +14,7 @@
 
 #include "gemm_core.h"
 #include "conv_gemm_policy.h"
+#include "stream_gemm.h"
 
 namespace fhip
 {
@@ -32,6 +33,30 @@ static bool conv_small_m(int K) { return K <= 64; }
 using ConvShapeNarrow = GemmShape<64, 32, 16, 2, 1, 8>;
 static bool conv_narrow_n(long long ntot) { return ntot <= 32; }
 
+// ---- the register-streamed 1x1 route (stream_gemm.h) ----------------------------------------------------------------------------
+// eligible: a pure function of the geometry (decides the packed-weight size); profitable: where it was measured faster than the
+// LDS-tiled kernel (deep reduction, narrow-to-medium output) -- both independent of everything but the param and the batch, so that
+// GetBufferSize, Init and Forward agree.
+static bool stream_eligible(const fhip_conv_param& p)
+{
+    return p.group == 1 && p.kernel_h == 1 && p.kernel_w == 1 && p.stride_h <= 1 && p.stride_w <= 1 && p.pad_left == 0 && p.pad_right == 0 &&
+           p.pad_top == 0 && p.pad_bottom == 0 && p.input_channels % 16 == 0 && p.output_channels % 32 == 0 && (p.output_h * p.output_w) % 4 == 0 &&
+           p.output_h == p.input_h && p.output_w == p.input_w;
+}
+static bool stream_profitable(const fhip_conv_param& p, int batch)
+{
+    return stream_eligible(p) && p.input_channels >= 256 && p.output_channels >= 128 && p.output_channels <= 512 &&
+           (long long)batch * p.output_h * p.output_w >= 4096;
+}
+void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
+size_t igemm_packed_floats(const fhip_conv_param& p)
+{
+    int kdp, kp;
+    igemm_packed_dims(p, &kdp, &kp);
+    // [ Wt: the LDS-tiled kernel's panels | wp: the streamed kernel's A-operand image (eligible 1x1 layers only) ]
+    return (size_t)kdp * kp + (stream_eligible(p) ? (size_t)p.output_channels * p.input_channels : 0);
+}
+
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
 {
     const int Kd = p.input_channels * p.kernel_h * p.kernel_w;
@@ -44,6 +69,7 @@ void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
 // k-tiles each); the reduction is cut into S equal parts, S a divisor of the k-tile count.
 static int igemm_split(const fhip_conv_param& p, int batch)
 {
+    if (stream_profitable(p, batch)) return 1; // the streamed kernel never splits
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
     const long long ntot = (long long)batch * p.output_h * p.output_w;
@@ -64,6 +90,8 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     want = std::min(want, kt / 8); // at least 8 k-tiles per piece
     return std::max(want, 1);
 }
+
+bool igemm_streams(const fhip_conv_param& p, int batch) { return stream_profitable(p, batch); }
 
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
 {
@@ -112,6 +140,12 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
     FHIP_CHECK_HIP(hipMemsetAsync(packed, 0, (size_t)kdp * kp * sizeof(float), s));
     hipLaunchKernelGGL(igemm_pack_weights_kernel, dim3(ceil_div(p.output_channels, 256), std::min(Kd, 65535)), dim3(256), 0, s, packed, kernel,
                        p.output_channels, Kd, kdp, conv_small_m(p.output_channels) ? 64 : 128);
+    if (stream_eligible(p))
+    {
+        const size_t kc = (size_t)p.output_channels * p.input_channels;
+        hipLaunchKernelGGL(stream_pack_weights_kernel, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, s, packed + (size_t)kdp * kp, kernel,
+                           p.output_channels, p.input_channels);
+    }
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -440,6 +474,38 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     {
         StageTimer tm(FHIP_STAGE_IGEMM, s);
         return smallc_forward(p, batch, out, in, packed, bias, g.relu, s);
+    }
+    if (!residual && stream_profitable(p, batch))
+    {
+        StreamGemmParams q;
+        q.in = in;
+        q.wp = packed + (size_t)kdp * g.Kp;
+        q.out = out;
+        q.bias = bias;
+        q.C = g.C;
+        q.K = g.K;
+        q.HW = g.OHW;
+        q.total_px = ntot;
+        q.mgroups = g.K / 32;
+        q.px_tiles = (int)((ntot + 127) / 128);
+        const unsigned blocks = (unsigned)q.px_tiles * (unsigned)((q.mgroups + 3) / 4);
+        StageTimer tm(FHIP_STAGE_IGEMM, s);
+#define FHIP_STREAM(D_, B_, R_) hipLaunchKernelGGL((stream_gemm_kernel<D_, B_, R_>), dim3(blocks), dim3(256), 0, s, q)
+        const int pick = ((g.C % 32) == 0 ? 4 : 0) | (g.has_bias ? 2 : 0) | (g.relu ? 1 : 0);
+        switch (pick)
+        {
+            case 7: FHIP_STREAM(16, true, true); break;
+            case 6: FHIP_STREAM(16, true, false); break;
+            case 5: FHIP_STREAM(16, false, true); break;
+            case 4: FHIP_STREAM(16, false, false); break;
+            case 3: FHIP_STREAM(8, true, true); break;
+            case 2: FHIP_STREAM(8, true, false); break;
+            case 1: FHIP_STREAM(8, false, true); break;
+            default: FHIP_STREAM(8, false, false); break;
+        }
+#undef FHIP_STREAM
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
     }
     g.split_k = igemm_split(p, batch);
     if (g.split_k > 1 && !buffer) return fail(FHIP_E_BADARG, "this geometry runs split-K and needs the scratch buffer GetBufferSize asked for");

@@ -171,13 +171,18 @@ FHIP_API int fhip_stage_timing_collect(double* ms, long long* launches);
 
 FHIP_API const char* fhip_last_error(void);
 FHIP_API const char* fhip_version(void);
+/* Introspection: 1 when fhip_conv_forward runs this IM2COL / NAIVE layer at this batch through the register-streamed 1x1 GEMM
+ * (stream_gemm.h: 1x1, stride 1, unpadded, C % 16 == 0, K % 32 == 0, Ho*Wo % 4 == 0, C >= 256, 128 <= K <= 512, >= 4096 pixels in the
+ * batch) instead of the LDS-tiled implicit GEMM.  Same result up to the summation order (tests/test_stream_gemm_gpu.py). */
+FHIP_API int fhip_conv_streams_1x1(const fhip_conv_param* param, int algo, int batch);
+
 /* name (>= 64 bytes), compute units, LDS bytes per CU; returns FHIP_E_NODEVICE if there is no GPU. */
 FHIP_API int fhip_device_info(char* name, int name_len, int* compute_units, int* lds_bytes);
 /* Calibration (measurement aid, ~10 ms): runs a kernel that is nothing but v_mfma_f32_32x32x2_f32 chains -- random U(-1,1) operands in
  * registers, four independent accumulators per wave, 3 waves per SIMD on every CU, i.e. the residency of the library's GEMM kernels --
  * and reports the best of 11 repetitions: *tflops = what the fp32 matrix pipe of THIS device sustains, *shader_mhz = shader-clock
  * ticks per 100 MHz wall-clock tick inside the kernel (s_memtime / s_memrealtime).  The nominal peak (157.3 TFLOP/s on MI355X) assumes
- * 2.4 GHz; under full-chip fp32 MFMA load the part clocks to its power budget.  Measured on MI355X: 126-138 TFLOP/s with random operands
+ * 2.4 GHz; under full-chip fp32 MFMA load the part clocks to its power budget.  Measured on MI355X: 126-147 TFLOP/s with random operands, depending on the box and its thermal state
  * (149-156 with constant ones -- dynamic power follows operand toggling), so that, not the nominal figure, is what a perfect
  * MFMA-bound kernel could reach on real data.  bench.py reports both. */
 FHIP_API int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream);

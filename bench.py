@@ -335,7 +335,7 @@ def attribute(net, reps):
                                    stage["wino_gemm"], "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
                                    "sum of their tile-GEMM HIP-event durations on the launch stream"))
     if pw_flops and pw_ms:
-        r = roofline_mfma("1x1 implicit GEMM: gemm_mfma_kernel<ConvGemmPolicy<1|2>> (+ split-K reduce)", pw_flops, pw_ms,
+        r = roofline_mfma("1x1 implicit GEMM: gemm_mfma_kernel<ConvGemmPolicy<1|2>> (+ split-K reduce) / stream_gemm_kernel (C >= 256, 128 <= K <= 512)", pw_flops, pw_ms,
                           "ConvParam::GetFLOPS 2*K*C*Ho*Wo*N summed over the 1x1 convolution layers of a step / sum of their per-layer "
                           "HIP-event durations (bias, ReLU, folded BatchNorm and fused residual included)")
         r["layers"] = len(pw_rows)

@@ -38,6 +38,7 @@ __global__ void stream_pack_weights(float* wp, const float* w, int K, int C)
 }
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef f32x16s st_acc_t;
 // measurement: every 64th block adds its shader-clock and 100 MHz wall-clock ticks (first wave): effective shader clock of the kernel
 static __device__ unsigned long long g_stream_clock_probe[2];
 // hipcc sinks ordinary loads towards their uses (it kept two of the eight float4 of the ring in flight): the ring is written with
@@ -309,5 +310,138 @@ __global__ __launch_bounds__(256) void stream_pw_split_kernel(const StreamParams
         }
         *reinterpret_cast<float4*>(op + (size_t)row * q.HW) = v;
     }
+}
+
+// ---- persistent variant: a wave walks TPW pixel tiles of its m-group (tiles pt, pt + tile_stride, ...) with the request ring running
+// across tile boundaries: the first D steps of the next tile are requested during the last D steps of this one, so neither the
+// prologue latency nor the 16 stores of the epilogue leave the matrix pipe idle.  Stores count in vmcnt like loads and retire in
+// order with them: the first D waits of a tile allow 16 more outstanding operations (the stores issued just before).
+struct StreamTiles
+{
+    int tiles_per_wave, tile_stride; // wave w of m-group g handles pixel tiles first, first + tile_stride, ...
+};
+
+#define STREAM_STEP(WAITN, LDB, LDA)                                                \
+    STREAM_WAIT(WAITN, b[u], a[u]);                                                  \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].x, acc[0], 0, 0, 0);    \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].y, acc[1], 0, 0, 0);    \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].z, acc[2], 0, 0, 0);    \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u].w, acc[3], 0, 0, 0);    \
+    STREAM_LD4(b[u], LDB);                                                           \
+    STREAM_LD1(a[u], LDA)
+
+template <int D>
+__global__ __launch_bounds__(256) void stream_pw_persistent_kernel(const StreamParams q, const StreamTiles ts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mg_blocks = (q.mgroups + 3) / 4;
+    int vid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qx = nwg / 8, rx = nwg % 8, xcd = vid % 8, local = vid / 8;
+        vid = ((xcd < rx) ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + local;
+    }
+    const int pt0 = vid / mg_blocks, mg = (vid - pt0 * mg_blocks) * 4 + wave;
+    if (mg >= q.mgroups || pt0 >= q.px_tiles) return;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float* ap = q.wp + (size_t)mg * (q.C / 2) * 64 + lane;
+    const size_t bstep = (size_t)2 * q.HW;
+    const int J = q.C / 2; // >= 2 * D, a multiple of D
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bs[r] = q.bias[32 * mg + 4 * half + (r & 3) + 8 * (r >> 2)];
+
+    // per-lane addresses of a pixel tile
+    auto locate = [&](int pt, const float*& bp, float*& op, bool& ok) {
+        const long long g = (long long)pt * 128 + 4 * l31;
+        ok = g < q.total_px;
+        const long long gc = ok ? g : 0;
+        const int n = (int)(gc / q.HW), p = (int)(gc - (long long)n * q.HW);
+        bp = q.in + ((size_t)n * q.C + half) * q.HW + p;
+        op = q.out + ((size_t)n * q.K + 32 * mg + 4 * half) * q.HW + p;
+    };
+    const float* bp;
+    float* op;
+    bool ok;
+    locate(pt0, bp, op, ok);
+
+    st_acc_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4s b[D];
+    float a[D];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+    {
+        STREAM_LD4(b[u], bp + (size_t)u * bstep);
+        STREAM_LD1(a[u], ap + (size_t)u * 64);
+    }
+    int pt = pt0;
+    for (int i = 0; i < ts.tiles_per_wave; ++i)
+    {
+        const int ptn = pt + ts.tile_stride;
+        const bool more = (i + 1 < ts.tiles_per_wave) && ptn < q.px_tiles;
+        const float* bpn;
+        float* opn;
+        bool okn;
+        locate(more ? ptn : pt, bpn, opn, okn);
+        // first D steps: behind the previous tile's 16 stores (none before the first tile)
+        {
+            const float* bnext = bp + (size_t)D * bstep;
+            const float* anext = ap + (size_t)D * 64;
+            if (i == 0)
+            {
+#pragma unroll
+                for (int u = 0; u < D; ++u) { STREAM_STEP(2 * D - 2, bnext + (size_t)u * bstep, anext + (size_t)u * 64); }
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0; u < D; ++u) { STREAM_STEP(2 * D - 2 + 16, bnext + (size_t)u * bstep, anext + (size_t)u * 64); }
+            }
+        }
+        // middle
+        {
+            const float* bnext = bp + (size_t)2 * D * bstep;
+            const float* anext = ap + (size_t)2 * D * 64;
+            for (int j0 = D; j0 < J - D; j0 += D)
+            {
+#pragma unroll
+                for (int u = 0; u < D; ++u) { STREAM_STEP(2 * D - 2, bnext + (size_t)u * bstep, anext + (size_t)u * 64); }
+                bnext += (size_t)D * bstep;
+                anext += (size_t)D * 64;
+            }
+        }
+        // last D steps: request the first D steps of the next tile (of this one again when there is none: drained below)
+#pragma unroll
+        for (int u = 0; u < D; ++u) { STREAM_STEP(2 * D - 2, bpn + (size_t)u * bstep, ap + (size_t)u * 64); }
+        // epilogue: 16 stores (lane 0 of a tile is always inside the tensor, so the stores are always issued)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            const int row = (r & 3) + 8 * (r >> 2);
+            float4 v = make_float4(acc[0][r] + bs[r], acc[1][r] + bs[r], acc[2][r] + bs[r], acc[3][r] + bs[r]);
+            if (q.relu)
+            {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+            }
+            if (ok) *reinterpret_cast<float4*>(op + (size_t)row * q.HW) = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        if (!more) break;
+        pt = ptn;
+        bp = bpn;
+        op = opn;
+        ok = okn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the requests made for a tile that does not exist
 }
 } // namespace fhip

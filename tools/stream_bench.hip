@@ -1,4 +1,4 @@
-// stream_bench.hip -- the register-streamed 1x1 GEMM experiment (tools/experiments/stream_gemm.h) against the product's implicit GEMM
+// stream_bench.hip -- the register-streamed 1x1 GEMM experiment (tools/experiments/stream_gemm_exp.h) against the product's implicit GEMM
 // (C-ABI) on the 1x1 / stride-1 shapes of ResNet-50 b64 and MobileNet-V1 b256.   stream_bench [reps] [name filter]
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "feather_hip/feather_hip.h"
-#include "stream_gemm.h"
+#include "stream_gemm_exp.h"
 
 using namespace fhip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -75,6 +75,18 @@ static void launch_split(const StreamParams& q)
     hipLaunchKernelGGL((stream_pw_split_kernel<D, SPLIT>), dim3((unsigned)(q.px_tiles * mg_blocks)), dim3(256), lds, 0, q);
 }
 
+template <int D>
+static void launch_persistent(const StreamParams& q, int slots)
+{
+    // one wave per (m-group, starting pixel tile); the starting tiles are spread so that all waves are resident at once
+    const int mg_blocks = (q.mgroups + 3) / 4;
+    int starts = std::max(1, std::min(q.px_tiles, slots / (mg_blocks * 4)));
+    StreamTiles ts;
+    ts.tile_stride = starts;
+    ts.tiles_per_wave = (q.px_tiles + starts - 1) / starts;
+    hipLaunchKernelGGL((stream_pw_persistent_kernel<D>), dim3((unsigned)(starts * mg_blocks)), dim3(256), 0, 0, q, ts);
+}
+
 static void run(const Case& cs)
 {
     if ((cs.H * cs.H) % 4) return; // the experiment needs 16-byte aligned pixel groups inside one image
@@ -128,10 +140,10 @@ static void run(const Case& cs)
     vars.push_back({"product (C-ABI)", [&] { CF(fhip_conv_forward(&p, FHIP_IM2COL, cs.N, out_ref, in, packed, buf, bias, nullptr)); }});
     vars.push_back({"stream D8 w4", [&] { launch_stream<8, 4, 1>(q); }});
     vars.push_back({"stream D16 w4", [&] { launch_stream<16, 4, 1>(q); }});
-    if (cs.C >= 32) vars.push_back({"split2 D8", [&] { launch_split<8, 2>(q); }});
-    if (cs.C >= 64) vars.push_back({"split4 D8", [&] { launch_split<8, 4>(q); }});
-    if (cs.C >= 128) vars.push_back({"split4 D16", [&] { launch_split<16, 4>(q); }});
-    if (cs.C >= 64) vars.push_back({"split2 D16", [&] { launch_split<16, 2>(q); }});
+    if (cs.C >= 32) vars.push_back({"persistent D8 3072", [&] { launch_persistent<8>(q, 3072); }});
+    if (cs.C >= 32) vars.push_back({"persistent D8 2048", [&] { launch_persistent<8>(q, 2048); }});
+    if (cs.C >= 64) vars.push_back({"persistent D16 3072", [&] { launch_persistent<16>(q, 3072); }});
+    if (cs.C >= 32) vars.push_back({"persistent D8 6144", [&] { launch_persistent<8>(q, 6144); }});
     std::vector<std::vector<double>> ms(vars.size());
     for (int round = 0; round < 3; ++round)
         for (size_t v = 0; v < vars.size(); ++v)

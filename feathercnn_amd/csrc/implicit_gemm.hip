@@ -40,8 +40,8 @@ static bool conv_narrow_n(long long ntot) { return ntot <= 32; }
 static bool stream_eligible(const fhip_conv_param& p)
 {
     return p.group == 1 && p.kernel_h == 1 && p.kernel_w == 1 && p.stride_h <= 1 && p.stride_w <= 1 && p.pad_left == 0 && p.pad_right == 0 &&
-           p.pad_top == 0 && p.pad_bottom == 0 && p.input_channels % 16 == 0 && p.output_channels % 32 == 0 && (p.output_h * p.output_w) % 4 == 0 &&
-           p.output_h == p.input_h && p.output_w == p.input_w;
+           p.pad_top == 0 && p.pad_bottom == 0 && p.input_channels % 16 == 0 && p.output_channels % 32 == 0 && p.output_h * p.output_w >= 4 &&
+           p.output_h == p.input_h && p.output_w == p.input_w; // Ho*Wo % 4 != 0 runs the RAGGED form of the kernel
 }
 static bool stream_profitable(const fhip_conv_param& p, int batch)
 {
@@ -485,12 +485,19 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
         q.C = g.C;
         q.K = g.K;
         q.HW = g.OHW;
-        q.total_px = ntot;
+        const bool ragged = (g.OHW % 4) != 0;
+        q.gpi = (g.OHW + 3) / 4;
+        q.total_px = ragged ? (long long)batch * q.gpi * 4 : ntot;
         q.mgroups = g.K / 32;
-        q.px_tiles = (int)((ntot + 127) / 128);
+        q.px_tiles = (int)((q.total_px + 127) / 128);
         const unsigned blocks = (unsigned)q.px_tiles * (unsigned)((q.mgroups + 3) / 4);
         StageTimer tm(FHIP_STAGE_IGEMM, s);
-#define FHIP_STREAM(D_, B_, R_) hipLaunchKernelGGL((stream_gemm_kernel<D_, B_, R_>), dim3(blocks), dim3(256), 0, s, q)
+#define FHIP_STREAM(D_, B_, R_)                                                                                     \
+    do                                                                                                              \
+    {                                                                                                               \
+        if (ragged) hipLaunchKernelGGL((stream_gemm_kernel<D_, B_, R_, true>), dim3(blocks), dim3(256), 0, s, q);   \
+        else hipLaunchKernelGGL((stream_gemm_kernel<D_, B_, R_, false>), dim3(blocks), dim3(256), 0, s, q);         \
+    } while (0)
         const int pick = ((g.C % 32) == 0 ? 4 : 0) | (g.has_bias ? 2 : 0) | (g.relu ? 1 : 0);
         switch (pick)
         {

@@ -37,9 +37,10 @@ struct StreamGemmParams
     const float* bias; // [K] (read only when the kernel is instantiated with BIAS)
     float* out;        // [N][K][HW]
     int C, K, HW;
-    long long total_px; // N * HW
+    long long total_px; // N * HW  (RAGGED: N * 4 * ceil(HW / 4) pixel SLOTS)
     int mgroups;        // K / 32
     int px_tiles;       // ceil(total_px / 128)
+    int gpi;            // RAGGED: pixel groups per image = ceil(HW / 4)
 };
 
 __global__ __launch_bounds__(256) void stream_pack_weights_kernel(float* __restrict__ wp, const float* __restrict__ w, int K, int C)
@@ -64,7 +65,11 @@ __global__ __launch_bounds__(256) void stream_pack_weights_kernel(float* __restr
 
 // D = depth of the request ring (steps in flight per wave); C / 2 must be a multiple of D.  Block = 4 waves = 4 consecutive m-groups of
 // one pixel tile (they read the same activation lines at about the same time: L1 / L2 hits); no wave ever waits for another.
-template <int D, bool BIAS, bool RELU>
+// RAGGED: Ho*Wo is not a multiple of 4 (ResNet-50's 7x7 stage: 49).  Every image then has ceil(HW / 4) pixel groups; the last one
+// would run past the image, so it is loaded SHIFTED BACK to the image's last four pixels (all loads stay inside the tensor) and only
+// its new pixels -- the trailing components -- are stored, one dword each.  Rows are then only 4-byte aligned: the float4 loads and
+// stores are unaligned, which the hardware takes.
+template <int D, bool BIAS, bool RELU, bool RAGGED = false>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamGemmParams q)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,7 +81,20 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamGemmParams
     const long long g = (long long)pt * 128 + 4 * l31;
     const bool ok = g < q.total_px;
     const long long gc = ok ? g : 0; // lanes beyond the tensor stream pixel group 0 and store nothing
-    const int n = (int)(gc / q.HW), p = (int)(gc - (long long)n * q.HW);
+    int n, p, first_new = 0;         // first_new: first component of this group that no earlier group covers
+    if (RAGGED)
+    {
+        const long long grp = gc >> 2;
+        n = (int)(grp / q.gpi);
+        const int gi = (int)(grp - (long long)n * q.gpi);
+        p = min(4 * gi, q.HW - 4);
+        first_new = 4 * gi - p;
+    }
+    else
+    {
+        n = (int)(gc / q.HW);
+        p = (int)(gc - (long long)n * q.HW);
+    }
     const float* bp = q.in + ((size_t)n * q.C + half) * q.HW + p;
     const float* ap = q.wp + (size_t)mg * (q.C / 2) * 64 + lane;
     const size_t bstep = (size_t)2 * q.HW;
@@ -138,7 +156,15 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamGemmParams
             v.z = fmaxf(v.z, 0.f);
             v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(op + (size_t)row * q.HW) = v;
+        float* o = op + (size_t)row * q.HW;
+        if (!RAGGED || first_new == 0)
+            *reinterpret_cast<float4*>(o) = v;
+        else
+        {
+            if (first_new <= 1) o[1] = v.y;
+            if (first_new <= 2) o[2] = v.z;
+            o[3] = v.w;
+        }
     }
 }
 #undef FHIP_ST_LD4

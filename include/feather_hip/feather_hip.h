@@ -172,7 +172,7 @@ FHIP_API int fhip_stage_timing_collect(double* ms, long long* launches);
 FHIP_API const char* fhip_last_error(void);
 FHIP_API const char* fhip_version(void);
 /* Introspection: 1 when fhip_conv_forward runs this IM2COL / NAIVE layer at this batch through the register-streamed 1x1 GEMM
- * (stream_gemm.h: 1x1, stride 1, unpadded, C % 16 == 0, K % 32 == 0, Ho*Wo % 4 == 0, C >= 256, 128 <= K <= 512, >= 4096 pixels in the
+ * (stream_gemm.h: 1x1, stride 1, unpadded, C % 16 == 0, K % 32 == 0, Ho*Wo >= 4, C >= 256, 128 <= K <= 512, >= 4096 pixels in the
  * batch) instead of the LDS-tiled implicit GEMM.  Same result up to the summation order (tests/test_stream_gemm_gpu.py). */
 FHIP_API int fhip_conv_streams_1x1(const fhip_conv_param* param, int algo, int batch);
 

@@ -35,6 +35,11 @@ ON_ROUTE = [
     ("no_bias", 256, 128, 16, 16, 16, False, True),
     ("no_relu", 256, 192, 16, 18, 15, True, False),
     ("mb_512_512", 512, 512, 14, 14, 32, True, True),
+    # Ho*Wo % 4 != 0: the last pixel group of every image is loaded shifted back and stores only its new pixels
+    ("deep_7x7_b256", 1024, 512, 7, 7, 256, True, True),           # 49 = 12 groups + 1 pixel
+    ("ragged_54", 256, 128, 6, 9, 80, True, True),                # 54 = 13 groups + 2 pixels
+    ("ragged_27_no_bias", 512, 256, 3, 9, 160, False, False),      # 27 = 6 groups + 3 pixels
+    ("ragged_ring_8", 272, 160, 5, 5, 170, True, True),            # 25 = 6 groups + 1 pixel, 8-deep ring
 ]
 
 
@@ -64,7 +69,7 @@ OFF_ROUTE = [
     ("shallow_c", 128, 128, 28, 28, 64),
     ("wide_k", 256, 1024, 14, 14, 64),
     ("narrow_k", 256, 64, 56, 56, 64),
-    ("odd_plane", 512, 256, 7, 7, 128),     # Ho*Wo % 4 != 0
+    ("tiny_plane", 512, 256, 1, 3, 2000),   # fewer than 4 pixels per image
     ("few_pixels", 512, 256, 14, 14, 8),
     ("k_not_32", 512, 144, 14, 14, 64),
 ]

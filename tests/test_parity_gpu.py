@@ -364,3 +364,12 @@ def test_winograd_shapes_the_reference_crashes_on(g, batch, cuda, port):
     assert used == oracle.WINOGRADF63
     assert nerr(y, port.forward(g, x, w, b)) <= TOL
     assert nerr(y, port.direct_f64(g, x, w, b)) <= TOL
+
+
+def test_mfma_calibration_reports_a_plausible_ceiling(cuda):
+    """fhip_calibrate_mfma_f32: a pure-MFMA kernel cannot beat the nominal fp32 matrix peak of the part (157.3 TFLOP/s on MI355X) and a
+    healthy device sustains well over half of it; bench.py prints this number next to every MFMA roofline."""
+    from feathercnn_amd import booster
+    tf, mhz = booster.calibrate_mfma_f32()
+    assert 60.0 < tf < 165.0, tf
+    assert 1000.0 < mhz < 3000.0, mhz

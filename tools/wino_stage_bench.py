@@ -10,6 +10,7 @@ from feathercnn_amd.booster import WINOGRADF63, stage_timing, stage_timing_colle
 
 which = sys.argv[1] if len(sys.argv) > 1 else "r50"
 SHAPES = {"r50": [(64, 64, 56, 64), (128, 128, 28, 64), (256, 256, 14, 64), (512, 512, 7, 64)],
+          "mall": [(64, 64, 224, 32), (64, 64, 224, 16), (64, 64, 224, 8), (64, 64, 224, 4), (64, 128, 112, 32), (64, 128, 112, 8), (128, 128, 112, 32), (128, 128, 112, 8)],
           "vgg": [(64, 64, 224, 32), (64, 128, 112, 32), (128, 128, 112, 32), (128, 256, 56, 32), (256, 256, 56, 32), (256, 512, 28, 32),
                   (512, 512, 28, 32), (512, 512, 14, 32)]}[which]
 dev = torch.device("cuda:0")

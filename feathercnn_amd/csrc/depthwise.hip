@@ -289,6 +289,183 @@ __global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams 
     }
 }
 
+// 3x3, pad 1 on every side, stride 1 / 2 on small SQUARE planes whose size is a compile-time constant (HH = 7, 14, 28: the last
+// three stages of MobileNet-V1, 70 % of its depthwise bytes).  Round 3.  A tensor of such planes is ONE contiguous stream (a 14 x 14
+// plane is 49 float4), so the block copies a chunk of whole planes to LDS with fully coalesced 16-byte loads -- every request of
+// the chunk in flight before the first LDS write -- and every lane then produces FOUR CONSECUTIVE outputs of the flat output stream:
+//   * stride 1, HW % 4 == 0: the input window of outputs f .. f+3 is three 6-float runs of the flat LDS image (f-W-1.., f-1..,
+//     f+W-1..): 18 LDS dwords for 36 FMAs; row / column validity is a mask on the value, not on the address, so a group that wraps
+//     from one image row into the next (14-pixel rows are 3.5 float4 long) needs no special case;
+//   * otherwise (stride 2, or 7 x 7 planes whose 49 floats make groups straddle planes) each output decodes its own (plane, y, x)
+//     with constant divisions and reads its 9 taps;
+//   * the four results leave as one 16-byte store of the contiguous output stream.
+// Against the direct kernel (lane = VX x R patch: 7 or 3 lanes per image row, 8-byte loads, three runtime integer divisions per
+// item) and the generic chunk kernel above (per-output decode with runtime divisions, 18 LDS reads per output): tools/dw_bench.hip.
+template <int HH, int S, int UNR>
+__global__ __launch_bounds__(256) void depthwise3x3_flat_kernel(const DwParams q, int chunk_planes, int chunks)
+{
+    constexpr int WW = HH, HW = HH * WW, OH = (HH - 1) / S + 1, OW = OH, OHW = OH * OW;
+    constexpr int PAD = (WW + 1 + 3) / 4 * 4; // reads of masked taps reach WW + 1 floats before / WW + 4 after the chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile_floats = chunk_planes * HW; // a multiple of 4 floats (host: chunk_planes % 4 == 0 unless HW % 4 == 0)
+    float* const tile = smem + PAD;
+    float* const wl = tile + tile_floats + PAD + 4; // [chunk_planes][12]: 9 taps, 3 unused
+    float* const bl = wl + chunk_planes * 12;       // [chunk_planes] bias
+    const int tid = threadIdx.x;
+
+    // A block walks chunks blockIdx.x, + gridDim.x, ...; the requests of the NEXT chunk (planes, taps, bias) are issued before this
+    // chunk's arithmetic, so a resident block always has loads in flight (a block that loads, computes and stores one chunk in
+    // sequence leaves the memory pipe idle for two thirds of its life).
+    f32x4 v[UNR], wv; // (native vectors: an array of HIP float4 structs carried around the chunk loop is not promoted to registers)
+    float bv;
+    // (a macro, not a lambda: a by-reference capture of v[] sends the array to scratch memory)
+#define FHIP_DW_REQUEST(chunk_)                                                                                   \
+    {                                                                                                             \
+        const int rq_plane0 = (chunk_)*chunk_planes;                                                              \
+        const int rq_np = min(chunk_planes, q.planes - rq_plane0);                                                \
+        const f32x4* rq_src = reinterpret_cast<const f32x4*>(q.in + (size_t)rq_plane0 * HW); /* 16-B aligned */  \
+        const int rq_n4 = (rq_np * HW) >> 2;                                                                      \
+        _Pragma("unroll") for (int b = 0; b < UNR; ++b) v[b] = rq_src[min(tid + b * 256, rq_n4 - 1)];            \
+        /* taps: plane pl is channel (plane0 + pl) % C; w12 rows are 3 float4 each */                             \
+        const int rq_pl = min(tid / 3, rq_np - 1), rq_part = tid - (tid / 3) * 3;                                 \
+        wv = reinterpret_cast<const f32x4*>(q.w12 + (size_t)((rq_plane0 + rq_pl) % q.C) * 12)[rq_part];          \
+        bv = q.has_bias ? q.bias[(rq_plane0 + min(tid, rq_np - 1)) % q.C] : 0.f;                                  \
+    }
+    int chunk = blockIdx.x;
+    if (chunk < chunks) FHIP_DW_REQUEST(chunk)
+    for (; chunk < chunks; chunk += gridDim.x)
+    {
+        const int plane0 = chunk * chunk_planes;
+        const int np = min(chunk_planes, q.planes - plane0);
+        const int nf = np * HW, n4 = nf >> 2;
+        {
+            f32x4* dst = reinterpret_cast<f32x4*>(tile);
+#pragma unroll
+            for (int b = 0; b < UNR; ++b)
+                if (tid + b * 256 < n4) dst[tid + b * 256] = v[b];
+            for (int i = (n4 << 2) + tid; i < nf; i += 256) tile[i] = q.in[(size_t)plane0 * HW + i]; // last chunk of a ragged tensor only
+            if (tid < 3 * np) reinterpret_cast<f32x4*>(wl)[tid] = wv;
+            if (tid < np) bl[tid] = bv;
+        }
+        __syncthreads();
+        if (chunk + (int)gridDim.x < chunks) FHIP_DW_REQUEST(chunk + (int)gridDim.x)
+        const int nout = np * OHW;
+        float* const obase = q.out + (size_t)plane0 * OHW; // 16-byte aligned
+        for (int o0 = tid * 4; o0 < nout; o0 += 1024)
+        {
+            float res[4];
+            if constexpr (S == 1 && (HW % 4) == 0)
+            {
+                // the four outputs share a plane; output flat index == input flat index
+                const int pl = o0 / HW, r = o0 - pl * HW;
+                const int y0 = r / WW, x0 = r - y0 * WW;
+                const float4* w4 = reinterpret_cast<const float4*>(wl + pl * 12);
+                const float4 wa = w4[0], wb = w4[1], wc = w4[2];
+                const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
+                const float bias = bl[pl];
+                float t[3][6];
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) t[m][j] = tile[o0 + (m - 1) * WW - 1 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const bool wrap = x0 + e >= WW;
+                    const int x = wrap ? x0 + e - WW : x0 + e, y = wrap ? y0 + 1 : y0;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                    {
+                        const bool rowok = (unsigned)(y + m - 1) < (unsigned)HH;
+#pragma unroll
+                        for (int n = 0; n < 3; ++n)
+                        {
+                            const bool ok = rowok && (unsigned)(x + n - 1) < (unsigned)WW;
+                            acc += (ok ? t[m][e + n] : 0.f) * w[m * 3 + n];
+                        }
+                    }
+                    res[e] = apply_act(acc + bias, q.relu);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const int o = min(o0 + e, nout - 1);
+                    const int pl = o / OHW, r = o - pl * OHW;
+                    const int oy = r / OW, ox = r - oy * OW;
+                    const float* wp = wl + pl * 12;
+                    const float* ip = tile + pl * HW + (oy * S - 1) * WW + ox * S - 1;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                    {
+                        const bool rowok = (unsigned)(oy * S + m - 1) < (unsigned)HH;
+#pragma unroll
+                        for (int n = 0; n < 3; ++n)
+                        {
+                            const bool ok = rowok && (unsigned)(ox * S + n - 1) < (unsigned)WW;
+                            acc += (ok ? ip[m * WW + n] : 0.f) * wp[m * 3 + n];
+                        }
+                    }
+                    res[e] = apply_act(acc + bl[pl], q.relu);
+                }
+            }
+            if (o0 + 3 < nout)
+                *reinterpret_cast<float4*>(obase + o0) = make_float4(res[0], res[1], res[2], res[3]);
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (o0 + e < nout) obase[o0 + e] = res[e];
+            }
+        }
+        if (chunk + (int)gridDim.x < chunks) __syncthreads(); // every lane is done with this chunk's LDS image
+    }
+#undef FHIP_DW_REQUEST
+}
+
+// LDS bytes of the flat kernel for a chunk of `cp` planes of HH x HH
+static inline size_t dw_flat_lds_bytes(int hh, int cp)
+{
+    const int pad = (hh + 1 + 3) / 4 * 4;
+    return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13) * sizeof(float);
+}
+
+// does the flat kernel take this geometry?  3x3, pad 1 on every side, stride 1 / 2, square planes of 7, 14 or 28 pixels
+static inline bool dw_flat_applicable(const DwParams& q, int pad_right, int pad_bottom)
+{
+    return q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1 && q.PT == 1 && pad_right == 1 && pad_bottom == 1 &&
+           q.H == q.W && (q.H == 7 || q.H == 14 || q.H == 28);
+}
+
+// launch the flat kernel on `grid` persistent blocks with chunks of `cp` planes (cp * H*W % 4 == 0, cp <= 85, cp * H*W <= 6 * 1024)
+static inline void dw_flat_launch(const DwParams& q, int cp, int grid, hipStream_t s)
+{
+    const int chunks = ceil_div(q.planes, cp);
+    const int unr = ceil_div(cp * q.H * q.W / 4, 256);
+    const size_t lds = dw_flat_lds_bytes(q.H, cp);
+    grid = std::min(grid, chunks);
+#define FHIP_FLAT_U(H_, S_, U_) hipLaunchKernelGGL((depthwise3x3_flat_kernel<H_, S_, U_>), dim3(grid), dim3(256), lds, s, q, cp, chunks)
+#define FHIP_FLAT(H_, S_)                        \
+    switch (unr)                                 \
+    {                                            \
+        case 1: FHIP_FLAT_U(H_, S_, 1); break;   \
+        case 2: FHIP_FLAT_U(H_, S_, 2); break;   \
+        case 3: FHIP_FLAT_U(H_, S_, 3); break;   \
+        case 4: FHIP_FLAT_U(H_, S_, 4); break;   \
+        case 5: FHIP_FLAT_U(H_, S_, 5); break;   \
+        default: FHIP_FLAT_U(H_, S_, 6); break;  \
+    }
+    if (q.H == 7) { if (q.SH == 1) { FHIP_FLAT(7, 1) } else { FHIP_FLAT(7, 2) } }
+    else if (q.H == 14) { if (q.SH == 1) { FHIP_FLAT(14, 1) } else { FHIP_FLAT(14, 2) } }
+    else { if (q.SH == 1) { FHIP_FLAT(28, 1) } else { FHIP_FLAT(28, 2) } }
+#undef FHIP_FLAT
+#undef FHIP_FLAT_U
+}
+
 // Small planes of any shape (7x7, 14x14 stride 2, 5x5 kernels ...): same chunk-of-whole-planes staging, then ONE
 // output per lane with lanes along the flattened output index, so the LDS reads of a wave are consecutive
 // addresses (stride SW) and the global stores are consecutive dwords.  planes_per_chunk is a multiple of 4,

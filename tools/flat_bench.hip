@@ -15,6 +15,7 @@
 #include "flat_gemm.h"
 #include "wave_gemm.h"
 #include "conv_gemm_policy.h"
+#include "gemm_core_probe.h"
 
 using namespace fhip;
 
@@ -170,7 +171,7 @@ static void launch_core_conv(const FlatConvParams& f, const float* in, float* ou
     g.k_tiles = f.Kdp / 16;
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = (g.Ntot + Shape::BN - 1) / Shape::BN;
-    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>, ABL, TUNE>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
+    hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, ConvGemmPolicy<MODE>, ABL, TUNE>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
 }
 
 static void run_conv(const ConvCase& cs, int rounds)

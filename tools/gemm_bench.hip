@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "gemm_core.h"
+#include "gemm_core_probe.h"
 #include "wino_gemm_policy.h"
 #include "wino_gemm_glds.h"
 
@@ -69,7 +70,7 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
         else if constexpr (V0 == 6)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 3>), grid, dim3(256), 0, 0, g);
         else
-            hipLaunchKernelGGL((gemm_mfma_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
+            hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
     };
     hipEvent_t a, b;
     CK(hipEventCreate(&a));

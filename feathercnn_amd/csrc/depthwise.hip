@@ -5,7 +5,9 @@
 // in fp32, + bias[c], ReLU, floor output dims -- but no padded copy of the input: padding is a bounds check.
 //
 // This is an HBM-bound kernel (9 FMA per 8 bytes moved): the whole job is to move each input and output element once.
-// Three forms live here, chosen by shape (measurements in DESIGN.md 3.3):
+// Four forms live here, chosen by shape (measurements in DESIGN.md 3.3):
+//   * depthwise3x3_flat_kernel    -- 3x3, stride 1/2, pad 1, 14 x 14 and 28 x 28 planes: a chunk of whole planes staged in LDS with
+//     coalesced 16-byte loads, four consecutive outputs of the flat output stream per lane (round 3).
 //   * depthwise3x3_direct_kernel  -- 3x3, stride 1/2, pad_left 1 (the MobileNet shapes).  NO LDS: every lane produces
 //     a VX-wide x R-high output patch straight from global memory with aligned vector loads, takes its two halo taps
 //     per row from the neighbouring lanes (cross-lane moves, not loads), and stores R vectors.
@@ -289,6 +291,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams 
     }
 }
 
+#ifndef FHIP_DW_FLAT_MINW
+#define FHIP_DW_FLAT_MINW 1
+#endif
 // 3x3, pad 1 on every side, stride 1 / 2 on small SQUARE planes whose size is a compile-time constant (HH = 7, 14, 28: the last
 // three stages of MobileNet-V1, 70 % of its depthwise bytes).  Round 3.  A tensor of such planes is ONE contiguous stream (a 14 x 14
 // plane is 49 float4), so the block copies a chunk of whole planes to LDS with fully coalesced 16-byte loads -- every request of
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams 
 // Against the direct kernel (lane = VX x R patch: 7 or 3 lanes per image row, 8-byte loads, three runtime integer divisions per
 // item) and the generic chunk kernel above (per-output decode with runtime divisions, 18 LDS reads per output): tools/dw_bench.hip.
 template <int HH, int S, int UNR>
-__global__ __launch_bounds__(256) void depthwise3x3_flat_kernel(const DwParams q, int chunk_planes, int chunks)
+__global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kernel(const DwParams q, int chunk_planes, int chunks)
 {
     constexpr int WW = HH, HW = HH * WW, OH = (HH - 1) / S + 1, OW = OH, OHW = OH * OW;
     constexpr int PAD = (WW + 1 + 3) / 4 * 4; // reads of masked taps reach WW + 1 floats before / WW + 4 after the chunk
@@ -630,7 +635,17 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     // small stride-2 planes (MobileNet's 14 x 14 -> 7 x 7, where a lane of the direct kernel has only 2 x 2 outputs to amortise its halo
     // loads over): the chunk-of-planes kernel; everything else: the direct kernel
     const bool small_plane = k3 && q.SH == 2 && HW <= kDwChunkMaxPlane;
-    if (small_plane)
+    // 14 x 14 and 28 x 28 planes, pad 1 all round (MobileNet-V1's conv6 ... conv13, 63 % of the depthwise bytes that stay depthwise
+    // launches in the fused net): the flat kernel.  Chunk sizes measured on MI355X, tensors NOT resident in the memory-side cache
+    // (tools/dw_bench.hip, b256): 28 px s1 73 us vs 107 us for the direct kernel, s2 50 vs 67; 14 px s1 40 vs 70, s2 26 vs 34 (chunk
+    // kernel).  One chunk per block: persistent blocks with the next chunk prefetched were slower at every grid size.  7 x 7 planes stay
+    // on the direct kernel (34 vs 39 us cache-resident, which is how the net finds them).
+    if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && q.H != 7)
+    {
+        const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : (q.SH == 1 ? 15 : 20);
+        dw_flat_launch(q, cp, 0x7fffffff, s);
+    }
+    else if (small_plane)
     {
         // ~3136 floats (12.25 KB) of planes per block: 4 x 28^2, 16 x 14^2, 64 x 7^2; a multiple of 4 planes keeps every chunk
         // 16-byte aligned whatever HW is

@@ -102,6 +102,44 @@ __attribute__((visibility("default"))) double ref_net_time(void* handle, int rep
     return best;
 }
 
+// The named blob of the LAST forward (ref_net_run / ref_net_time*), no new forward: several blobs of one reference run.
+__attribute__((visibility("default"))) long ref_net_extract(void* handle, const char* output_name, float* out, long capacity, int* dims)
+{
+    Quiet q;
+    feather::Net* net = static_cast<feather::Net*>(handle);
+    float* ptr = nullptr;
+    int n = 0, oc = 0, oh = 0, ow = 0;
+    if (net->Extract(std::string(output_name), &ptr, &n, &oc, &oh, &ow) != 0) return -3;
+    const long count = (long)n * oc * oh * ow;
+    if (count > capacity) return -4;
+    memcpy(out, ptr, sizeof(float) * count);
+    if (dims)
+    {
+        dims[0] = n;
+        dims[1] = oc;
+        dims[2] = oh;
+        dims[3] = ow;
+    }
+    return count;
+}
+
+// `warmup` untimed forwards, then `reps` forwards timed one by one (seconds each -> secs[0 .. reps)) on the image already fed
+// (warm-up 1 + >= 3 timed reps, clock_gettime like the reference's helper.cpp:89-98).
+__attribute__((visibility("default"))) void ref_net_time_each(void* handle, int warmup, int reps, double* secs)
+{
+    Quiet q;
+    feather::Net* net = static_cast<feather::Net*>(handle);
+    for (int r = 0; r < warmup; ++r) net->Forward();
+    for (int r = 0; r < reps; ++r)
+    {
+        timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        net->Forward();
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        secs[r] = (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+    }
+}
+
 __attribute__((visibility("default"))) void ref_net_close(void* handle)
 {
     Quiet q;

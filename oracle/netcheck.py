@@ -41,6 +41,10 @@ class RefNet:
         lib.ref_net_time.restype = ctypes.c_double
         lib.ref_net_time.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ref_net_close.argtypes = [ctypes.c_void_p]
+        lib.ref_net_extract.restype = ctypes.c_long
+        lib.ref_net_extract.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_int)]
+        lib.ref_net_time_each.restype = None
+        lib.ref_net_time_each.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         self.lib = lib
         if param_path is not None:
             self.h = lib.ref_net_open(param_path.encode(), bin_path.encode())
@@ -66,8 +70,27 @@ class RefNet:
             outs.append(buf[:n].reshape(dims[1], dims[2], dims[3]).copy())
         return np.stack(outs)
 
+    def run_blobs(self, input_name: str, image: np.ndarray, names, capacity: int = 1 << 24):
+        """ONE reference forward of one image [c][h][w]; the named blobs of that run, each as [1][c][h][w]."""
+        first = self.run(input_name, image[None], names[0], capacity)
+        outs = [first]
+        for nm in names[1:]:
+            buf = np.empty(capacity, np.float32)
+            dims = (ctypes.c_int * 4)()
+            n = self.lib.ref_net_extract(self.h, nm.encode(), buf.ctypes.data_as(ctypes.c_void_p), capacity, dims)
+            if n < 0:
+                raise RuntimeError(f"ref_net_extract rc={n}")
+            outs.append(buf[:n].reshape(1, dims[1], dims[2], dims[3]).copy())
+        return tuple(outs)
+
     def time_forward(self, reps: int = 3) -> float:
         return self.lib.ref_net_time(self.h, reps)
+
+    def time_each(self, warmup: int = 1, reps: int = 3):
+        """`warmup` untimed + `reps` individually timed forwards of the image already fed -> list of seconds."""
+        secs = (ctypes.c_double * reps)()
+        self.lib.ref_net_time_each(self.h, warmup, reps, secs)
+        return list(secs)
 
     def close(self):
         if self.h:

@@ -1,8 +1,9 @@
 """Oracle parity AT the BASELINE.json shapes: what bench.py times is what gets checked.
 
 (i)  The three metric nets at their bench configuration -- 224x224, the bench batch (VGG-16 32, ResNet-50 64,
-     MobileNet-V1 256), fusion level 3, MI355X conv routing, branch concurrency, hipGraph replay -- against the REAL reference
-     feather::Net (oracle/_ref, N = 1) on a few images of the batch (first, middle, last): logits and probabilities.
+     MobileNet-V1 256), bench.SUB_BATCHES replicas, fusion level 3, MI355X conv routing, branch concurrency, hipGraph replay --
+     against the REAL reference feather::Net (oracle/_ref, N = 1): every image of VGG-16's batch, 16+ spread images of the others
+     (both sides of the replica split included): logits and probabilities.
 (ii) One layer per route at the FULL benchmark batch with the real reference looped over the whole batch (no sampling):
      VGG conv1_2 / conv5_1 b32 (Winograd), ResNet-50 1x1 stride-1 / stride-2 b64 (implicit GEMM), MobileNet depthwise b256.
 
@@ -20,13 +21,33 @@ TOL = 1e-4
 BENCH_NETS = [("vgg16", 32, "fc8"), ("resnet50", 64, "fc1000"), ("mobilenet_v1", 256, "fc7")]
 
 
+def bench_picks(batch, replicas, every):
+    """Images of the batch that are checked: all of them (VGG-16), or 16 spread over the batch including its first and last image and
+    BOTH sides of every replica boundary (the sub-batch replicas deal the batch out in contiguous shares)."""
+    if every:
+        return list(range(batch))
+    from feathercnn_amd.shard import shard_range
+    picks = {0, batch - 1}
+    for r in range(replicas):
+        lo, hi = shard_range(batch, r, replicas)
+        picks.update((lo, hi - 1))
+    step = max(1, batch // 16)
+    picks.update(range(step // 2, batch, step))
+    return sorted(picks)
+
+
 @pytest.mark.parametrize("name,batch,logits", BENCH_NETS, ids=[n for n, _, _ in BENCH_NETS])
 def test_bench_configuration_matches_reference_net(cuda, name, batch, logits):
+    """EXACTLY the configuration bench.py times (bench.DEFAULT_BATCH, bench.SUB_BATCHES, fusion 3, MI355X routing, branch stream, graph
+    replay): every image of VGG-16's batch, >= 16 spread images of the other two, against the real reference feather::Net."""
+    import bench
     from feathercnn_amd.net import Net
+    assert batch == bench.DEFAULT_BATCH[name]
+    replicas = bench.SUB_BATCHES.get(name, 1)
     model = model_zoo.MODELS[name]()  # 224 x 224
     p, b, i, o = model
     x = np.random.default_rng(2024).uniform(-1, 1, (batch, 3, 224, 224)).astype(np.float32)
-    net = Net(fusion=3, graph=True, tuned=True, concurrency=True)  # exactly bench.py's setup_net
+    net = Net(fusion=3, graph=True, tuned=True, concurrency=True, sub_batches=replicas)  # exactly bench.py's measure_net
     net.LoadParam(p)
     net.LoadWeights(b)
     net.FeedInput(i, x)
@@ -34,10 +55,11 @@ def test_bench_configuration_matches_reference_net(cuda, name, batch, logits):
         net.Forward()
     prob, got_logits = net.Extract(o), net.Extract(logits)
     assert prob.shape[0] == batch and np.isfinite(prob).all()
-    picks = [0, batch // 2 - 1, batch - 1]
+    picks = bench_picks(batch, replicas, every=(name == "vgg16"))
+    assert len(picks) >= min(batch, 16)
     if netcheck.have_ref_net():
         ref = netcheck.RefNet(p, b)
-        want = [(ref.run(i, x[k:k + 1], o), ref.run(i, x[k:k + 1], logits)) for k in picks]
+        want = [ref.run_blobs(i, x[k], (o, logits)) for k in picks]  # one reference forward per image, both blobs
         ref.close()
     else:  # the restatement (slower): one image
         picks = picks[:1]

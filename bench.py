@@ -46,6 +46,7 @@ DEFAULT_BATCH = {"vgg16": 32, "resnet50": 64, "mobilenet_v1": 256, "squeezenet_v
 # sub-batch replicas of the net per GPU (fhip_net_set_sub_batches), measured with tools/dual_stream_bench.py: MobileNet-V1 b256 gains 8 %
 # with two (its HBM-bound depthwise kernels run under the other share's MFMA-bound 1x1 kernels), VGG-16 and ResNet-50 gain nothing
 SUB_BATCHES = {"mobilenet_v1": 2}
+STEADY_STEPS = 200  # length of the cross-check region timed after the contract's K steps ("steady_state" in the JSON line)
 
 
 def parse():
@@ -135,74 +136,50 @@ def cpu_baseline(net, procs):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def net_cpu_worker(args):
-    """One single-threaded process of the whole-net CPU baseline: the reference feather::Net on one image."""
-    param_path, bin_path, core, reps, in_name, out_name, shape = args
-    try:
-        os.sched_setaffinity(0, {core})
-    except Exception:
-        pass
-    os.environ["OMP_NUM_THREADS"] = "1"
-    import numpy as np
-    from oracle import netcheck
-    x = np.random.default_rng(core).uniform(-1, 1, (1,) + tuple(shape)).astype(np.float32)
-    if netcheck.have_ref_net():
-        ref = netcheck.RefNet(None, None, param_path, bin_path)
-        ref.run(in_name, x, out_name)           # Reshape + Init + first Forward (untimed)
-        t = ref.time_forward(reps)              # 1 warm-up + best of `reps`
-        ref.close()
-        return t
-    port = netcheck.PortNet(open(param_path, "rb").read(), open(bin_path, "rb").read())
-    t0 = time.perf_counter()
-    port.run(in_name, x, out_name)
-    return time.perf_counter() - t0
-
-
-def net_cpu_baseline(net_name, model, procs):
-    """The REAL reference runtime (feather::Net, AVX2) on this host: P independent single-thread processes, 1 image each."""
-    import multiprocessing as mp
+def net_cpu_baseline(net_name, model, procs, budget=30.0):
+    """The REAL reference runtime (feather::Net, AVX2) on this host's cores, SURVEY.md 8(d): the model is loaded once in a helper
+    process (oracle/cpu_bench.py: no torch, no HIP), which fork()s P single-thread workers pinned to distinct cores -- the weights are
+    shared copy-on-write -- for P in {1, 16, 64, 128, host cores}; every worker does 1 warm-up + 3 timed forwards of one image.
+    Reported: the best aggregate of the sweep with its P, the whole sweep, the one-core figure.  Bounded to ~`budget` seconds."""
+    import subprocess
     import tempfile
 
     from oracle import netcheck
     p, b, i, o = model
-    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    ncpu = len(cores)
-    avail = 0
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable"):
-                avail = int(line.split()[1]) * 1024
-    except OSError:
-        pass
-    per_proc = 6 * len(b) + (1 << 30)  # raw blobs + packed copies + transient Mat + python
-    procs = procs or max(1, min(ncpu, int(avail * 0.6 // per_proc) if avail else 8))
-    kind = "reference" if netcheck.have_ref_net() else "port"
-    reps = 1
-    ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
+    if not netcheck.have_ref_net():  # no compiled reference here: the restatement, one image, one core
+        import numpy as np
+        port = netcheck.PortNet(p, b)
+        x = np.random.default_rng(7).uniform(-1, 1, (1, 3, 224, 224)).astype(np.float32)
+        t0 = time.perf_counter()
+        port.run(i, x, o)
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": f"{net_name} whole net through the numpy/C restatement, 1 image, 1 process, {dt:.1f}s"}
     with tempfile.TemporaryDirectory() as d:
         pp, bp = os.path.join(d, "m.param"), os.path.join(d, "m.bin")
         open(pp, "wb").write(p)
         open(bp, "wb").write(b)
-        job = lambda c: (pp, bp, c, reps, i, o, (3, 224, 224))  # noqa: E731
-        with ctx.Pool(1) as pool:
-            single = pool.map(net_cpu_worker, [job(cores[0])])[0]
-        with ctx.Pool(procs) as pool:
-            per = pool.map(net_cpu_worker, [job(cores[k % ncpu]) for k in range(procs)])
-    wall = time.perf_counter() - t0
-    model_name = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model_name = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(sum(1.0 / t for t in per), 3), "unit": "images/s", "cores": procs, "kind": kind,
-            "sample": f"{net_name} whole net through the reference feather::Net (N = 1, no fusion: the reference never runs its "
-                      f"fusion pass), 1 image per process, {procs} independent single-thread processes pinned to distinct cores "
-                      f"(reference AVX Winograd is single-thread only), 1 warm-up + best of {reps} forwards each, {wall:.1f}s wall",
-            "single_core_images_per_s": round(1.0 / single, 3), "cpu_model": model_name, "host_cores": ncpu}
+        cmd = [sys.executable, "-m", "oracle.cpu_bench", "--param", pp, "--bin", bp, "--input", i, "--output", o, "--budget", str(budget)]
+        if procs:
+            cmd += ["--procs", f"1,{procs}"]
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=budget * 4 + 120)
+        wall = time.perf_counter() - t0
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline helper failed: " + out.stderr[-400:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    best = r["best"]
+    one = next((s_ for s_ in r["sweep"] if s_["procs"] == 1), None)
+    return {"value": best["images_per_s"], "unit": "images/s", "cores": best["procs"], "kind": "reference",
+            "sample": f"{net_name} whole net through the reference feather::Net (N = 1, no fusion: the reference never runs its fusion pass), "
+                      f"1 image per process; model loaded once, then P fork()ed single-thread workers pinned to distinct cores (weights shared "
+                      f"copy-on-write; the reference's AVX Winograd is single-thread only); {r['warmup']} warm-up + {r['reps']} timed forwards "
+                      f"per worker, aggregate = sum of 1 / mean forward time; best of the sweep P = {[s_['procs'] for s_ in r['sweep']]}"
+                      + (f" (P = {r['skipped_for_time']} skipped: time cap {r['budget_s']:.0f}s)" if r["skipped_for_time"] else "")
+                      + f"; {r['sweep_s']:.1f}s sweep + {r['load_s']:.1f}s load, {wall:.1f}s wall",
+            "sweep": r["sweep"], "single_core_images_per_s": one["images_per_s"] if one else None, "cpu_model": r["cpu_model"],
+            "host_cores": r["host_cores"]}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -407,7 +384,7 @@ def timed_region(step, steps, warmup, env):
     return dt
 
 
-def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail=True):
+def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail=True, steady=0):
     """One benchmark network through the feather::Net runtime: build (rank 0) + one RCCL broadcast of the .bin, timed region,
     per-kernel attribution.  -> result dict (rank 0 carries the detail)."""
     import numpy as np
@@ -444,6 +421,12 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     res = {"net": net_name, "images_per_s": round(total_images * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
            "warmup": warmup, "per_gpu_batch": nb, "global_batch": total_images, "scaling": "strong" if global_batch else "weak",
            "sub_batches": replicas}
+    if steady:
+        # cross-check of the contract's K-step figure: the same bracketed region again, long enough (>= 0.5 s of GPU time) that clock
+        # ramp and launch jitter average out.  `value` stays the K-step number.
+        n2 = max(steady, steps)
+        dt2 = timed_region(net.Forward, n2, 0, env)
+        res["steady_state"] = {"steps": n2, "images_per_s": round(total_images * n2 / dt2, 2), "ms_per_step": round(dt2 / n2 * 1e3, 4)}
     if rank == 0 and detail:
         if replicas > 1:
             # kernels of concurrent replicas share the chip, so their individual durations are not a roofline measurement: the
@@ -636,13 +619,13 @@ def main():
         model, extras = None, {}
     else:
         # ---- headline: BASELINE.json configs[1] (VGG-16, 32 images per GPU) unless --net says otherwise; weak scaling at N > 1
-        head, model = measure_net(head_net, a, env, a.steps, a.warmup, a.global_batch, a.batch)
+        head, model = measure_net(head_net, a, env, a.steps, a.warmup, a.global_batch, a.batch, steady=STEADY_STEPS)
         extras = {}
         if not explicit and not a.headline_only:
             # ---- the other nets BASELINE.json's metric names, same process, same timing procedure
             if world == 1:
-                for name in ("resnet50", "mobilenet_v1"):
-                    extras[name], _ = measure_net(name, a, env, a.steps, a.warmup)
+                for name in ("resnet50", "mobilenet_v1"):  # not the contract's headline: never fewer than 100 timed steps
+                    extras[name], _ = measure_net(name, a, env, max(a.steps, 100), a.warmup, steady=STEADY_STEPS)
                 # the one-GPU point of configs[4]'s strong-scaling curve (ResNet-50, 512 images in total)
                 extras["resnet50_global512"], _ = measure_net("resnet50", a, env, max(a.steps // 5, 5), max(a.warmup // 2, 1), global_batch=512,
                                                               detail=False)
@@ -681,10 +664,10 @@ def main():
         res["traffic_note"] = TRAFFIC_NOTE
         res["mfma_calibration"] = dict(sustained_mfma(), note="fhip_calibrate_mfma_f32: a kernel of nothing but v_mfma_f32_32x32x2_f32 chains at 3 "
                                        "waves per SIMD on every CU; its TFLOP/s and the shader clock it ran at (nominal peak 157.3 TFLOP/s assumes 2.4 GHz)")
-        nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches")}}
+        nets_out = {head_net: {k: head[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches", "steady_state") if k in head}}
         tables = {head_net: table}
         for name, e in extras.items():
-            nets_out[name] = {k: e[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches", "steps", "warmup") if k in e}
+            nets_out[name] = {k: e[k] for k in ("images_per_s", "ms_per_step", "per_gpu_batch", "global_batch", "scaling", "sub_batches", "steps", "warmup", "steady_state") if k in e}
             for k in ("workload", "stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "device_memory"):
                 if k in e:
                     nets_out[name][k] = e[k]

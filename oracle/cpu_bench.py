@@ -1,0 +1,136 @@
+"""oracle.cpu_bench -- TEST / BENCH INFRASTRUCTURE ONLY: the CPU-baseline leg of bench.py (SURVEY.md 8(d) "CPU baseline timing").
+
+The REAL reference runtime (feather::Net + AVX2 booster, oracle/_ref/libfeather_net_ref.so, compiled from /root/reference) is
+single-threaded on AVX, so the multi-core figure is P independent single-thread copies pinned to distinct cores,
+images/s summed.  This helper
+
+  * loads the model ONCE (LoadParam / LoadWeights / Init + one forward), then fork()s the P workers: the weights and packed kernels
+    are shared copy-on-write, so P processes do not hold P copies of a 550 MB model (the round-2 leg spent its time and the host's
+    memory bandwidth on exactly that);
+  * sweeps P over an ascending list, each worker doing 1 untimed warm-up + `reps` (>= 3) individually timed forwards
+    (clock_gettime inside the shim, like the reference's helper.cpp:89-98);  aggregate(P) = sum over workers of 1 / mean(times);
+  * stops the sweep when the next P would not fit the time budget (predicted from the previous P) and says which were skipped; a worker
+    that runs into the deadline stops after the forward it is in (never fewer than one timed forward);
+  * prints ONE JSON object on stdout.
+
+It runs in a fresh interpreter WITHOUT torch / HIP (fork() from a process with GPU runtime threads is not safe), which is why it is a
+separate module:  python -m oracle.cpu_bench --param m.param --bin m.bin --input data --output prob [--procs 1,16,64,128,256]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+
+
+def worker(ref, core, reps, deadline, wfd):
+    try:
+        os.sched_setaffinity(0, {core})
+    except OSError:
+        pass
+    try:
+        secs = ref.time_each(1, 1)  # the untimed warm-up (it also takes this process's copy-on-write page faults) + the first timed forward
+        while len(secs) < reps and time.monotonic() < deadline:
+            secs += ref.time_each(0, 1)
+        os.write(wfd, struct.pack(f"<i{len(secs)}d", len(secs), *secs))
+    finally:
+        os._exit(0)
+
+
+def read_exact(fd, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = os.read(fd, n - len(buf))
+        if not chunk:
+            return None
+        buf += chunk
+    return buf
+
+
+def run_procs(ref, cores, procs, reps, deadline):
+    """fork `procs` workers (worker k on cores[k % len]), each: 1 warm-up + up to `reps` timed forwards (fewer only if the deadline
+    passes; never fewer than one) -> list of per-worker time lists, wall seconds."""
+    pipes = []
+    t0 = time.perf_counter()
+    for k in range(procs):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            worker(ref, cores[k % len(cores)], reps, deadline, w)
+        os.close(w)
+        pipes.append((pid, r))
+    out = []
+    for pid, r in pipes:
+        head = read_exact(r, 4)
+        body = read_exact(r, 8 * struct.unpack("<i", head)[0]) if head else None
+        os.close(r)
+        os.waitpid(pid, 0)
+        if body:
+            out.append(list(struct.unpack(f"<{len(body) // 8}d", body)))
+    return out, time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--param", required=True)
+    ap.add_argument("--bin", required=True)
+    ap.add_argument("--input", required=True)
+    ap.add_argument("--output", required=True)
+    ap.add_argument("--shape", default="3,224,224")
+    ap.add_argument("--procs", default="", help="ascending list of process counts (default: 1,16,64,128,<host cores>)")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--budget", type=float, default=30.0, help="seconds for the whole sweep (model load not included)")
+    a = ap.parse_args()
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+
+    from oracle import netcheck
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    ncpu = len(cores)
+    plist = [int(v) for v in a.procs.split(",") if v] if a.procs else [1, 16, 64, 128, ncpu]
+    plist = sorted({min(p, ncpu) for p in plist if p >= 1})
+    reps = max(3, a.reps)
+    shape = tuple(int(v) for v in a.shape.split(","))
+    t0 = time.perf_counter()
+    ref = netcheck.RefNet(None, None, a.param, a.bin)
+    x = np.random.default_rng(7).uniform(-1, 1, (1,) + shape).astype(np.float32)
+    ref.run(a.input, x, a.output)  # Reshape + Init + first forward, untimed
+    load_s = time.perf_counter() - t0
+    sweep, skipped = [], []
+    t_start = time.perf_counter()
+    prev = None  # (procs, wall seconds of that sweep point)
+    for p in plist:
+        elapsed = time.perf_counter() - t_start
+        if prev is not None and elapsed + prev[1] * max(1.0, (p / prev[0]) ** 0.5) > a.budget:
+            skipped.append(p)  # predicted from the previous point: memory-bound beyond a few cores, so a forward slows down as P grows
+            continue
+        times, wall = run_procs(ref, cores, p, reps, time.monotonic() + max(a.budget - elapsed, 1.0))
+        if len(times) != p:
+            skipped.append(p)
+            continue
+        means = [sum(t) / len(t) for t in times]
+        sweep.append({"procs": p, "images_per_s": round(sum(1.0 / m for m in means), 3), "mean_forward_s": round(sum(means) / len(means), 4),
+                      "best_forward_s": round(min(min(t) for t in times), 4), "timed_forwards_per_worker": min(len(t) for t in times),
+                      "wall_s": round(wall, 2)})
+        prev = (p, wall)
+    ref.close()
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    best = max(sweep, key=lambda r: r["images_per_s"]) if sweep else None
+    json.dump({"sweep": sweep, "skipped_for_time": skipped, "best": best, "reps": reps, "warmup": 1, "host_cores": ncpu, "cpu_model": model,
+               "load_s": round(load_s, 2), "sweep_s": round(time.perf_counter() - t_start, 2), "budget_s": a.budget}, sys.stdout)
+    sys.stdout.write("\n")
+
+
+if __name__ == "__main__":
+    main()

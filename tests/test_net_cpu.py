@@ -175,3 +175,31 @@ int main()
     subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I" + inc, str(mat_test), "-o", exe2], check=True, capture_output=True, text=True)
     out = subprocess.run([exe2], capture_output=True, text=True)
     assert out.returncode == 0 and "mat ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif(not netcheck.have_ref_net(), reason="needs the compiled reference (oracle/_ref)")
+def test_cpu_baseline_helper_sweeps_process_counts(tmp_path):
+    """bench.py's cpu_baseline leg (oracle/cpu_bench.py): model loaded once, fork()ed single-thread workers, 1 warm-up + 3 timed
+    forwards each, a sweep over process counts bounded by a time budget -- and the extract-only / per-forward-timing shim entries."""
+    import json
+    import subprocess
+    import sys
+    p, b, i, o = model_zoo.MODELS["squeezenet_v1.1"]()
+    pp, bp = tmp_path / "m.param", tmp_path / "m.bin"
+    pp.write_bytes(p)
+    bp.write_bytes(b)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--param", str(pp), "--bin", str(bp), "--input", i, "--output", o,
+                          "--procs", "1,2", "--budget", "60"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [s["procs"] for s in r["sweep"]] == [1, 2] and r["reps"] >= 3 and r["warmup"] == 1
+    assert all(s["timed_forwards_per_worker"] >= 3 and s["images_per_s"] > 0 for s in r["sweep"])
+    assert r["best"]["images_per_s"] == max(s["images_per_s"] for s in r["sweep"])
+    # several blobs of ONE reference forward == the blobs of separate runs
+    ref = netcheck.RefNet(p, b)
+    x = np.random.default_rng(3).uniform(-1, 1, (1, 3, 224, 224)).astype(np.float32)
+    prob, pool = ref.run_blobs(i, x[0], (o, "pool10"))
+    assert np.array_equal(prob, ref.run(i, x, o)) and np.array_equal(pool, ref.run(i, x, "pool10"))
+    assert len(ref.time_each(1, 3)) == 3
+    ref.close()

@@ -16,7 +16,11 @@
 //     512 contiguous bytes per half-wave, bias + ReLU applied on the way -- no transpose, no LDS;
 //   * loads are inline asm with counted waits: hipcc sinks ordinary loads towards their uses (it kept 2 of 8 float4 in flight).
 //     vmcnt retires in order, so with P requests outstanding `s_waitcnt vmcnt(P - 2)` says the oldest two (one B float4, one A dword)
-//     have landed; the registers are operands of the wait, so their uses cannot be hoisted above it.
+//     have landed; the registers are operands of the wait, so their uses cannot be hoisted above it.  What the language does NOT
+//     guarantee is that hipcc leaves a destination alone between its load and that wait (a register copy or a spill there would
+//     read stale data): that obligation is checked on the generated code of the shipped library by tools/check_stream_isa.py
+//     (a vmcnt-queue replay of every instantiation: no instruction touches a register with a load in flight, no scratch
+//     instructions), run by tests/test_boundary.py on every build -- re-run it after any compiler change.
 //
 // Measured against gemm_mfma_kernel<128x64, ConvGemmPolicy<2>> (tools/stream_bench.hip, MI355X): 1024 -> 256 @14x14 b64 70 vs 80 us
 // (+ 12 us of split-K reduce), 512 -> 128 @28x28 b64 72 vs 79, 512 -> 512 @14x14 b256 231 vs 240, 256 -> 256 @28x28 b256 232 vs 250;

@@ -195,3 +195,25 @@ def test_cpp_host_api_compiles_and_runs_like_convlayer(lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host api ok" in out.stdout
+
+
+def test_streamed_gemm_ring_registers_are_untouched_until_their_wait():
+    """stream_gemm.h keeps global loads in flight behind hipcc's back (inline asm destinations + counted
+    s_waitcnt).  The obligation -- no instruction touches a ring register between its load and the wait that retires it, no spills --
+    is a property of the generated code, so it is checked on the SHIPPED library's gfx950 code objects (tools/check_stream_isa.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_stream_isa", os.path.join(ROOT, "tools", "check_stream_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    # the checker itself: a copy out of a register with a load in flight is flagged, the same copy behind the wait is not
+    bad = [[0, "global_load_dwordx4", "v[4:7], v[0:1], off", None], [4, "v_mov_b32_e32", "v9, v5", None], [8, "s_waitcnt", "vmcnt(0)", None]]
+    good = [[0, "global_load_dwordx4", "v[4:7], v[0:1], off", None], [4, "s_waitcnt", "vmcnt(0)", None], [8, "v_mov_b32_e32", "v9, v5", None]]
+    ring = [[0, "global_load_dword", "v4, v[0:1], off", None], [4, "global_load_dword", "v5, v[0:1], off", None],
+            [8, "s_waitcnt", "vmcnt(1)", None], [12, "v_add_f32_e32", "v9, v4, v4", None], [16, "v_add_f32_e32", "v9, v5, v5", None]]
+    spill = [[0, "scratch_store_dword", "off, v3, off", None]]
+    assert chk.check_function("bad", bad)[0] and not chk.check_function("good", good)[0]
+    assert len(chk.check_function("ring", ring)[0]) == 1 and chk.check_function("spill", spill)[0]
+    loop = [[0, "global_load_dword", "v4, v[0:1], off", None], [4, "s_waitcnt", "vmcnt(0)", None], [8, "v_add_f32_e32", "v9, v4, v4", None],
+            [12, "global_load_dword", "v4, v[0:1], off", None], [16, "s_cbranch_scc1", "65532", 8]]  # the back edge re-reads v4 with its load in flight
+    assert any("steady state" in v for v in chk.check_function("loop", loop)[0])
+    assert chk.main(os.path.join(ROOT, "feathercnn_amd", "libfeather_hip.so")) == 0

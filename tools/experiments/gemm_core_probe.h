@@ -13,6 +13,10 @@ namespace fhip
 #ifdef FHIP_TIMELINE
 // measurement builds only (tools/flat_bench.hip, -DFHIP_TIMELINE, ABLATE bit 5): shader-clock stamps of sampled blocks
 static __device__ long long g_core_timeline[64][16];
+// ABLATE bit 6: EVERY block logs [hw id | 100 MHz wall clock at start, set-up done, k-tile 0 in LDS, k-loop done, end] -> g_core_blocklog[block][8]
+// (the life cycle of all blocks of a launch, grouped per CU on the host: tools/r50_probe.hip)
+static __device__ long long* g_core_blocklog;
+static __device__ long long* g_core_iterlog;
 #endif
 
 // TUNE (round 2, from per-block clock stamps -- tools/flat_bench.hip FLAT_CORE=1: a 128x64x64 tile of ResNet-50's 1x1 layers spent
@@ -43,6 +47,19 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     int tl_n = 0;
     auto stamp = [&]() {
         if ((ABLATE & 32) && tl_on && tl_n < 16) g_core_timeline[blockIdx.x / 97][tl_n] = clock64();
+        if ((ABLATE & 64) && threadIdx.x == 0)
+        {
+            long long* lg = g_core_blocklog + (size_t)blockIdx.x * 8;
+            if (tl_n == 0)
+            {
+                lg[0] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); // XCC_ID, HW_ID
+                lg[1] = wall_clock64();
+            }
+            else if (tl_n == 1) lg[2] = wall_clock64();
+            else if (tl_n == 2) lg[3] = wall_clock64();
+            else if (tl_n == 7) lg[4] = wall_clock64();
+            else if (tl_n == 15) lg[5] = wall_clock64();
+        }
         ++tl_n;
     };
 #else
@@ -98,6 +115,34 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
         }
     };
 
+    // ABLATE bit 8 (DEEP): a second register set, so the global loads of a k-tile have TWO iterations to land (a block whose iteration is
+    // shorter than the load latency is latency-bound whatever the matrix pipe does)
+    constexpr bool DEEP = (ABLATE & 256) != 0;
+    float4 pa2[Shape::A_PASSES];
+    BRaw pb2[Shape::B_PASSES];
+    unsigned pok2[Shape::B_PASSES];
+    auto fetch2 = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < Shape::A_PASSES; ++i) pa2[i] = aload.load(prm, kt * BK + a_r + i * Shape::A_ROWS_PER_PASS);
+#pragma unroll
+        for (int i = 0; i < Shape::B_PASSES; ++i) pb2[i] = bload.load(prm, kt * BK + b_r + i * Shape::B_ROWS_PER_PASS, pok2[i]);
+    };
+    auto stash2 = [&](int buf, int kt) {
+#pragma unroll
+        for (int i = 0; i < Shape::A_PASSES; ++i)
+            *reinterpret_cast<float4*>(&As0[buf * (BK * BM) + (a_r + i * Shape::A_ROWS_PER_PASS) * BM + a_c4 * 4]) = pa2[i];
+#pragma unroll
+        for (int i = 0; i < Shape::B_PASSES; ++i)
+        {
+            float4 v = bload.finish(prm, pb2[i], kt * BK + b_r + i * Shape::B_ROWS_PER_PASS, extra);
+            v.x = (pok2[i] & 1u) ? v.x : 0.f;
+            v.y = (pok2[i] & 2u) ? v.y : 0.f;
+            v.z = (pok2[i] & 4u) ? v.z : 0.f;
+            v.w = (pok2[i] & 8u) ? v.w : 0.f;
+            *reinterpret_cast<float4*>(&Bs0[buf * (BK * BN) + (b_r + i * Shape::B_ROWS_PER_PASS) * BN + b_c4 * 4]) = v;
+        }
+    };
+
     f32x16 acc[Shape::TM][Shape::TN];
 #pragma unroll
     for (int i = 0; i < Shape::TM; ++i)
@@ -122,7 +167,14 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             bias_r[i][q] = (TUNE & 2) ? Policy::bias_at(prm, m0 + wm * Shape::WTM + i * 32 + q * 8 + (lane >> 3)) : 0.f;
-    if (k_tiles > 1)
+    if (DEEP)
+    {
+        // set 1 (pa) holds tile 0 now; tile 1 -> set 2, tile 0 -> LDS, tile 2 -> set 1
+        if (k_tiles > 1) fetch2(1);
+        stash(0, 0);
+        if (k_tiles > 2) fetch(2);
+    }
+    else if (k_tiles > 1)
     {
         float4 qa[Shape::A_PASSES];
         BRaw qb[Shape::B_PASSES];
@@ -153,8 +205,25 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     for (int kt = 0; kt < k_tiles; ++kt)
     {
         // k-tile kt+1 (in registers since the previous iteration) -> the other LDS buffer; k-tile kt+2 -> registers
-        if (kt + 1 < k_tiles) stash(cur ^ 1, kt + 1);
-        if (kt + 2 < k_tiles && !(ABLATE & 1)) fetch(kt + 2);
+        if (DEEP)
+        {
+            // odd tiles live in set 2, even tiles in set 1; the set just emptied takes tile kt+3
+            if (kt & 1)
+            {
+                if (kt + 1 < k_tiles) stash(cur ^ 1, kt + 1);
+                if (kt + 3 < k_tiles) fetch(kt + 3);
+            }
+            else
+            {
+                if (kt + 1 < k_tiles) stash2(cur ^ 1, kt + 1);
+                if (kt + 3 < k_tiles) fetch2(kt + 3);
+            }
+        }
+        else
+        {
+            if (kt + 1 < k_tiles) stash(cur ^ 1, kt + 1);
+            if (kt + 2 < k_tiles && !(ABLATE & 1)) fetch(kt + 2);
+        }
 
         const float* as = As0 + cur * (BK * BM) + a_off;
         const float* bs = Bs0 + cur * (BK * BN) + b_off;
@@ -175,6 +244,10 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
         __syncthreads();
         cur ^= 1;
         if (kt < 4) stamp();
+#ifdef FHIP_TIMELINE
+        // ABLATE bit 7: wall clock at the end of EVERY k-tile of every block -> g_core_iterlog[block][64]
+        if ((ABLATE & 128) && threadIdx.x == 0 && kt < 64) g_core_iterlog[(size_t)blockIdx.x * 64 + kt] = wall_clock64();
+#endif
     }
     tl_n = 7;
     stamp(); // k-loop done

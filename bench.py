@@ -605,6 +605,19 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     env = {"dev": dev, "rank": rank, "world": world}
+    affinity = None
+    if world > 1 and not share:
+        # one process per GPU on a two-socket host: this rank's host thread stays on the cores of its GPU's NUMA node
+        from feathercnn_amd.shard import pin_rank_to_gpu_numa_node
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        try:
+            ids = []
+            for i in range(min(local_world, torch.cuda.device_count())):
+                pr = torch.cuda.get_device_properties(i)
+                ids.append(f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
+        except Exception:
+            ids = []
+        affinity = pin_rank_to_gpu_numa_node(local, local_world, ids)
     explicit = a.net is not None
     head_net = a.net or "vgg16"
 
@@ -648,6 +661,8 @@ def main():
                        "conv_routing": "reference SelectAlgo rule" if a.reference_selection else "fhip_conv_select_algo_tuned (Winograd also on 4..8-pixel 3x3 layers)",
                        "streams": "one" if (a.no_overlap or a.mode != "net") else "main + one side stream for arena-free branch convolutions"},
         }
+        if affinity is not None:
+            res["config"]["rank0_cpu_affinity"] = affinity
         table = head.pop("table", [])
         cpu_fn = head.pop("cpu_baseline_fn", None)
         for k in ("stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "conv_gflops_per_s_direct", "device_memory", "weight_broadcast"):

@@ -88,6 +88,7 @@ SIGNATURES = {
     "fhip_net_load_param_mem": (_I, [_V, ctypes.c_char_p, _SZ]),
     "fhip_net_load_weights": (_I, [_V, ctypes.c_char_p]),
     "fhip_net_load_weights_mem": (_I, [_V, _V, _SZ]),
+    "fhip_net_load_weights_device": (_I, [_V, _V, _SZ]),
     "fhip_net_feed_input": (_I, [_V, ctypes.c_char_p, _I, _I, _I, _I, _V, _I]),
     "fhip_net_forward": (_I, [_V]),
     "fhip_net_extract": (_I, [_V, ctypes.c_char_p, ctypes.POINTER(_V), _PI, _PI, _PI, _PI]),

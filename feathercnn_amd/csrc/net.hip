@@ -1597,6 +1597,19 @@ int fhip_net_load_weights_mem(fhip_net* n, const void* data, size_t len)
     return load_weights_mem(n->impl, data, len);
 }
 
+// The .bin image handed over in DEVICE memory -- the buffer an RCCL broadcast (ncclBroadcast of the model from rank 0)
+// delivered on this rank's GPU.  The image is staged through host memory once, because the loaders keep the raw weights on the host
+// until Init (BatchNorm / Scale folding into the convolution weights happens there); the caller keeps ownership of `device_data` and
+// may free it when the call returns.
+int fhip_net_load_weights_device(fhip_net* n, const void* device_data, size_t len)
+{
+    NET_GUARD(n);
+    if (!device_data && len) return fail(FHIP_E_BADARG, "null data");
+    std::vector<char> host(len);
+    if (len) FHIP_CHECK_HIP(hipMemcpy(host.data(), device_data, len, hipMemcpyDeviceToHost));
+    return fhip_net_load_weights_mem(n, host.data(), len);
+}
+
 int fhip_net_load_weights(fhip_net* n, const char* path)
 {
     NET_GUARD(n);

@@ -65,3 +65,59 @@ def broadcast_model(build, device=None, src: int = 0):
     if rank != src:
         model = (param, blob.cpu().numpy().tobytes(), i, o)
     return model, dt, blob.numel()
+
+
+# ---- host side of one-process-per-GPU: keep every rank's host thread (kernel launches, graph replays, input staging) on the cores of
+# ---- the NUMA node its GPU hangs off, and away from the other ranks' cores (an 8-GPU MI355X node is a 2-socket host)
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def rank_cpus(node_cpus, ranks_on_node: int, index_on_node: int, allowed=None):
+    """The contiguous share of a NUMA node's cores that the `index_on_node`-th of `ranks_on_node` ranks gets; restricted to `allowed`
+    (the cores the process may run on) and never empty while `allowed` leaves the node any core."""
+    cpus = sorted(c for c in node_cpus if allowed is None or c in allowed)
+    if not cpus or ranks_on_node < 1 or not (0 <= index_on_node < ranks_on_node):
+        return []
+    per = max(1, len(cpus) // ranks_on_node)
+    lo = min(index_on_node * per, len(cpus) - per)
+    return cpus[lo:lo + per]
+
+
+def gpu_numa_node(pci_bus_id: str):
+    """NUMA node of a PCI device ('0000:75:00.0'), or -1 when the platform does not say."""
+    try:
+        return int(open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node").read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def pin_rank_to_gpu_numa_node(local_rank: int, local_world: int, pci_bus_ids):
+    """os.sched_setaffinity for this rank: the cores of its GPU's NUMA node, split between the local ranks whose GPUs share that node.
+    `pci_bus_ids[i]` = PCI address of local rank i's device.  Falls back to an even split of the allowed cores when the platform
+    reports no NUMA nodes.  -> what was done (goes into bench.py's JSON line); never raises."""
+    import os
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        nodes = [gpu_numa_node(b) for b in pci_bus_ids]
+        mine = nodes[local_rank] if local_rank < len(nodes) else -1
+        if mine >= 0:
+            node_cpus = parse_cpulist(open(f"/sys/devices/system/node/node{mine}/cpulist").read())
+            peers = [r for r in range(local_world) if r < len(nodes) and nodes[r] == mine]
+            cpus = rank_cpus(node_cpus, len(peers), peers.index(local_rank), allowed)
+            how = f"NUMA node {mine} of GPU {pci_bus_ids[local_rank]}, share {peers.index(local_rank) + 1}/{len(peers)}"
+        else:
+            cpus = rank_cpus(sorted(allowed), local_world, local_rank, allowed)
+            how = f"no NUMA information: share {local_rank + 1}/{local_world} of the allowed cores"
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"pinned": bool(cpus), "cpus": f"{cpus[0]}-{cpus[-1]}" if cpus else "", "count": len(cpus), "how": how}
+    except Exception as e:  # affinity is an optimisation
+        return {"pinned": False, "error": repr(e)}

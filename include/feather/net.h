@@ -52,6 +52,8 @@ class Net
     int LoadWeights(FILE* fp) { return load_file(fp, false); }
     int LoadParamMem(const char* text, size_t len) { return fhip_net_load_param_mem(net_, text, len); }
     int LoadWeightsMem(const void* data, size_t len) { return fhip_net_load_weights_mem(net_, data, len); }
+    // the .bin image in device memory (the receive buffer of the RCCL weight broadcast, one rank per GPU)
+    int LoadWeightsDevice(const void* device_data, size_t len) { return fhip_net_load_weights_device(net_, device_data, len); }
 
     // Net::FeedInput(const char*, ncnn::Mat&), net.h:44 / net.cpp:235-246 + Blob::CopyFromMat (blob.cpp:71-95): a host Mat of
     // shape (w, h, c), fp32, copied channel by channel (the Mat's channel stride may be padded to 16 bytes).  -1 for an unknown

@@ -151,6 +151,11 @@ FHIP_API int fhip_net_load_param_mem(fhip_net* net, const char* text, size_t len
 /* Net::LoadWeights, net.cpp:172-233 (ncnn .bin read in layer order; ncnn/modelbin.cpp:47-197). */
 FHIP_API int fhip_net_load_weights(fhip_net* net, const char* path);
 FHIP_API int fhip_net_load_weights_mem(fhip_net* net, const void* data, size_t len);
+/* The same image in DEVICE memory of the current device: what `ncclBroadcast` of the .bin from rank 0 leaves on every rank
+ * (the one collective of the multi-GPU path; tests/cpp/multi_gpu_main.cpp, INTEGRATION.md "multi-GPU from C++").
+ * Staged through host memory once (weights stay on the host until Init folds BatchNorm / Scale into them); `device_data` stays the
+ * caller's and may be freed on return. */
+FHIP_API int fhip_net_load_weights_device(fhip_net* net, const void* device_data, size_t len);
 
 /* Net::FeedInput, net.cpp:235-246, extended with a batch.  `data` holds n*c*h*w floats; `on_device` says
  * whether it is a device pointer (copied device-to-device on the net's stream) or a host pointer. */

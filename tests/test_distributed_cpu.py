@@ -77,3 +77,22 @@ def test_two_ranks_gloo_broadcast_and_shard():
     assert abs(d0 - want) < 1e-9
     assert (lo0, hi0, lo1, hi1) == (0, 5, 5, 10)
     assert s0 == s1 == float(np.arange(30).sum())
+
+
+def test_rank_affinity_shares_numa_cores_between_local_ranks():
+    """bench.py pins every rank's host thread to the cores of its GPU's NUMA node (8 processes on a two-socket host): the split is
+    contiguous, disjoint between the ranks of a node, inside the allowed set, and never empty."""
+    from feathercnn_amd.shard import parse_cpulist, pin_rank_to_gpu_numa_node, rank_cpus
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    node0 = parse_cpulist("0-63,128-191")
+    shares = [rank_cpus(node0, 4, k) for k in range(4)]
+    assert all(len(s) == 32 for s in shares) and len(set().union(*map(set, shares))) == 128
+    assert rank_cpus(node0, 4, 1, allowed=set(range(8))) == [2, 3]          # a restricted cpuset is respected
+    assert rank_cpus([5], 3, 2) == [5] and rank_cpus([], 2, 0) == [] and rank_cpus(node0, 2, 2) == []
+    import os
+    before = os.sched_getaffinity(0)
+    try:
+        r = pin_rank_to_gpu_numa_node(1, 2, ["ffff:ff:1f.0", "ffff:ff:1e.0"])   # no such devices: falls back to an even split
+        assert r["pinned"] and r["count"] >= 1 and set(os.sched_getaffinity(0)) <= set(before)
+    finally:
+        os.sched_setaffinity(0, before)

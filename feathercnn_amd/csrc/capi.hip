@@ -446,18 +446,10 @@ __global__ __launch_bounds__(256) void mfma_calibration_kernel(float* sink, cons
 }
 } // namespace
 
-int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream)
+// the measurement proper; the caller owns (and always frees) the buffers and events
+static int calibrate_mfma_f32_run(float* sink, float* noise, hipEvent_t e0, hipEvent_t e1, int blocks, int steps, hipStream_t s, double* tflops,
+                                  double* shader_mhz)
 {
-    if (!tflops || !shader_mhz) return fail(FHIP_E_BADARG, "null argument");
-    int dev = 0;
-    FHIP_CHECK_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    FHIP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    hipStream_t s = (hipStream_t)stream;
-    const int blocks = prop.multiProcessorCount * 3, steps = 256; // 3 blocks of 4 waves per CU, 8192 MFMAs per wave: ~0.8 ms
-    float *sink = nullptr, *noise = nullptr;
-    FHIP_CHECK_HIP(hipMalloc((void**)&sink, 4));
-    FHIP_CHECK_HIP(hipMalloc((void**)&noise, 4096 * sizeof(float)));
     {
         std::vector<float> h(4096);
         unsigned x = 2463534242u;
@@ -471,9 +463,6 @@ int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream)
         FHIP_CHECK_HIP(hipMemcpyAsync(noise, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, s));
         FHIP_CHECK_HIP(hipStreamSynchronize(s));
     }
-    hipEvent_t e0, e1;
-    FHIP_CHECK_HIP(hipEventCreate(&e0));
-    FHIP_CHECK_HIP(hipEventCreate(&e1));
     const unsigned long long zero[2] = {0, 0};
     double best_tf = 0, best_mhz = 0;
     for (int rep = 0; rep < 12; ++rep) // the first repetition warms up; the power manager takes a few ms to settle: best of the rest
@@ -495,13 +484,33 @@ int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream)
             best_mhz = mhz;
         }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(sink);
-    (void)hipFree(noise);
     *tflops = best_tf;
     *shader_mhz = best_mhz;
     return FHIP_OK;
+}
+
+int fhip_calibrate_mfma_f32(double* tflops, double* shader_mhz, void* stream)
+{
+    if (!tflops || !shader_mhz) return fail(FHIP_E_BADARG, "null argument");
+    int dev = 0;
+    FHIP_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FHIP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount * 3, steps = 256; // 3 blocks of 4 waves per CU, 8192 MFMAs per wave: ~0.8 ms
+    float *sink = nullptr, *noise = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = FHIP_OK;
+    // every resource is released on every path
+    if (hipMalloc((void**)&sink, 4) != hipSuccess || hipMalloc((void**)&noise, 4096 * sizeof(float)) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess)
+        rc = fail(FHIP_E_HIP, "fhip_calibrate_mfma_f32: could not allocate its buffers / events");
+    else
+        rc = calibrate_mfma_f32_run(sink, noise, e0, e1, blocks, steps, (hipStream_t)stream, tflops, shader_mhz);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (sink) (void)hipFree(sink);
+    if (noise) (void)hipFree(noise);
+    return rc;
 }
 
 } // extern "C"

@@ -255,6 +255,9 @@ struct Blob
         h = h_;
         w = w_;
         alias = nullptr;
+        // a blob the previous plan chained away has no storage and, as a rule, will have none after this Reshape either: plan_chains
+        // allocates it afterwards if the new shapes un-chain it (no device malloc + free per chained blob and shape change)
+        if (chained && !data) return 0;
         if (count() > capacity)
         {
             if (data && capacity) (void)hipFree(data);
@@ -625,7 +628,16 @@ struct ConvLayer : Layer
     // absorb `elt` = Eltwise SUM of this layer's top and `other` (a blob produced earlier in the layer list)
     bool FuseResidual(Blob* other)
     {
-        if (pw || fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
+        if (pw)
+        {
+            // behind an absorbed 1x1 convolution (MobileNet-V2 style dw -> pw(linear) -> add): the add goes into the POINTWISE layer's
+            // epilogue; the pair then runs its two kernels one after the other (Reshape: pair_fast needs a pointwise layer without residual)
+            if (fuse_pool || residual || !pw->FuseResidual(other)) return false;
+            pw->bottoms.pop_back();   // the pointwise layer's bottoms are set per call (a stand-in for the depthwise output)
+            bottoms.push_back(other); // dependency scans look at THIS layer
+            return true;
+        }
+        if (fuse_pool || residual || p.activation != FHIP_ACT_NONE) return false;
         residual = other;
         bottoms.push_back(other); // so that dependency scans (fusion, branch concurrency) see the second input
         return true;
@@ -1287,6 +1299,7 @@ static int plan_chains(Net& net)
             conv[i]->chain_bytes = 0;
         }
     for (auto& kv : net.blobs) kv.second->chained = false;
+    for (auto& b : net.shadowed) b->chained = false; // blobs whose name a later top re-used (in-place style .param files) re-plan too
     net.chain_slot[0] = net.chain_slot[1] = net.chain_m = 0;
     if (net.fusion < 3) return 0;
     auto plain = [](const ConvLayer* c) { return c && !c->pw && !c->residual && c->algo_ == FHIP_WINOGRADF63 && c->tops.size() == 1 && c->bottoms.size() == 1; };
@@ -1306,6 +1319,17 @@ static int plan_chains(Net& net)
         a->tops[0]->chained = true;
         a->tops[0]->drop_storage();
     }
+    // blobs the previous plan had chained and this one did not: Reshape left them without storage
+    auto restore = [](Blob* b) -> int {
+        if (b->chained || b->data || b->alias || b->fused_away || b->count() == 0) return 0;
+        FHIP_CHECK_HIP(hipMalloc((void**)&b->data, b->count() * sizeof(float)));
+        b->capacity = b->count();
+        return 0;
+    };
+    for (auto& kv : net.blobs)
+        if (const int rc = restore(kv.second.get())) return rc;
+    for (auto& b : net.shadowed)
+        if (const int rc = restore(b.get())) return rc;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t slot[2] = {0, 0}, msz = 0;
     for (size_t i = 0; i < L; ++i)
@@ -1639,6 +1663,11 @@ int fhip_net_feed_input(fhip_net* n, const char* blob_name, int num, int c, int 
                 if (on_device) FHIP_CHECK_HIP(hipStreamWaitEvent(n->more[r]->impl.stream, n->fork, 0));
                 const int rc = fhip_net_feed_input(n->more[r].get(), blob_name, cnt, c, h, w, data + first * chw, on_device);
                 if (rc) return rc;
+                // join the replica's copy back into the net's stream: whatever the caller enqueues there next (re-using or overwriting
+                // the source buffer, a synchronize of the net's stream only) is ordered behind it -- "the caller's stream order is
+                // unchanged" holds for FeedInput too
+                FHIP_CHECK_HIP(hipEventRecord(n->joins[r], n->more[r]->impl.stream));
+                FHIP_CHECK_HIP(hipStreamWaitEvent(n->impl.stream, n->joins[r], 0));
             }
             first += cnt;
         }
@@ -1714,9 +1743,12 @@ int fhip_net_extract(fhip_net* n, const char* blob_name, float** ptr, int* num, 
         total += pieces.back().second;
         images += pn;
     }
+    // The returned pointer stays valid until the next FeedInput with a different shape (like a blob pointer of a plain net): the
+    // buffer of a name is only ever re-allocated when that blob's total size grows, which takes a new input shape.
     DeviceVec& g = n->gathered[blob_name];
     if (g.bytes < total * sizeof(float))
     {
+        FHIP_CHECK_HIP(hipStreamSynchronize(n->impl.stream)); // earlier gathers of this name may still be in flight
         const int rc = g.resize(total * sizeof(float));
         if (rc) return rc;
     }
@@ -1797,6 +1829,9 @@ int fhip_net_forward_timed(fhip_net* n, float* ms)
 {
     NET_GUARD(n);
     if (!ms) return fail(FHIP_E_BADARG, "null argument");
+    if (!n->more.empty())
+        return fail(FHIP_E_UNSUPPORTED, "per-layer timing of a net with sub-batch replicas: kernels of concurrent replicas share the chip, "
+                                        "so their durations are not layer times -- time a net created without fhip_net_set_sub_batches");
     Net& net = n->impl;
     int rc = prepare(net);
     if (rc) return rc;

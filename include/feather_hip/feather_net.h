@@ -142,7 +142,8 @@ FHIP_API int fhip_net_set_graph(fhip_net* net, int on);
  * equal the single-net ones up to the batch-dependent reduction order of split-K layers (<= 1e-6 normalised).  What it buys: kernels of
  * different character overlap (MobileNet-V1 b256: HBM-bound depthwise layers of one share under the MFMA-bound 1x1 layers of the
  * other, +8 % images/s with R = 2) and the tails of small launches are filled; nets made of long uniform launches gain nothing
- * (VGG-16, ResNet-50: +-1 %).  Set once, before LoadParam.  Introspection calls and fhip_net_forward_timed describe replica 0. */
+ * (VGG-16, ResNet-50: +-1 %).  Set once, before LoadParam.  Introspection calls describe replica 0; fhip_net_forward_timed refuses a net
+ * with replicas (kernels of concurrent replicas share the chip, their durations are not layer times). */
 FHIP_API int fhip_net_set_sub_batches(fhip_net* net, int replicas);
 
 /* Net::LoadParam, net.cpp:54-170 (ncnn text .param: magic 7767517, "layers blobs", one line per layer). */
@@ -165,7 +166,8 @@ FHIP_API int fhip_net_feed_input(fhip_net* net, const char* blob_name, int n, in
  * order on the net's stream.  Asynchronous: returns after enqueueing. */
 FHIP_API int fhip_net_forward(fhip_net* net);
 /* Net::Extract(name, float**, n, c, h, w), net.cpp:263-279: DEVICE pointer into the net's blob + its shape.
- * The pointer stays valid until the next Reshape. */
+ * The pointer stays valid until the next Reshape.  With sub-batch replicas the pointer is a per-name buffer the shares are gathered
+ * into (on the net's stream); it is re-allocated only when that blob's total size grows, i.e. after a FeedInput with a larger shape. */
 FHIP_API int fhip_net_extract(fhip_net* net, const char* blob_name, float** device_ptr, int* n, int* c, int* h, int* w);
 /* Convenience: synchronise the stream and copy the blob to a host buffer of `capacity` floats. */
 FHIP_API int fhip_net_extract_host(fhip_net* net, const char* blob_name, float* host, size_t capacity);

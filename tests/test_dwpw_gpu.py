@@ -116,3 +116,35 @@ def test_net_fusion_level_2_fuses_the_pairs_and_matches_level_1(cuda):
             assert names == [("dw0", True), ("dw1", True), ("dw3", True), ("dw4", True), ("dw_seq", False)], names  # dw2 (K = 64) is not absorbed
             assert [n for t, n, _ in net.layers() if t == "Convolution"] == ["conv1", "pw2", "pw_odd"]  # every other pointwise layer was absorbed
     assert nerr(outs[2], outs[1]) <= 1e-5
+
+
+def test_absorbed_pointwise_keeps_the_residual_fusion(cuda):
+    """MobileNet-V2 style block dw3x3 -> pw(linear) -> Eltwise SUM (-> ReLU) with 64 < K < 160: the depthwise layer absorbs the pointwise
+    one at LoadParam time, and the add still moves into the POINTWISE convolution's epilogue (it used to be refused, so the
+    block ran conv + a separate add); the pair then runs its two kernels inside one layer.  Levels 2 / 3 equal level 0 and the layer count
+    says the Eltwise layers are gone."""
+    from feathercnn_amd import model_zoo
+    from feathercnn_amd.net import Net
+    g = model_zoo.GraphBuilder(11)
+    x = g.input("data", 3, 32, 32)
+    x = g.conv_bn_relu("stem", x, 3, 96, 3, 1, 1)
+    for i in range(2):
+        a, b_ = g.split(f"split{i}", x)
+        y = g.conv_bn_relu(f"dw{i}", a, 96, 96, 3, 1, 1, group=96)
+        y = g.conv_bn_relu(f"pw{i}", y, 96, 96, 1, 1, 0, relu=False)      # linear bottleneck
+        x = g.eltwise(f"add{i}", y, b_)
+        if i == 1:
+            x = g.relu("add1_relu", x)
+    p, b = g.finish()
+    img = np.random.default_rng(12).uniform(-1, 1, (3, 3, 32, 32)).astype(np.float32)
+    outs, counts = {}, {}
+    for level in (0, 2, 3):
+        net = Net(fusion=level, tuned=True)
+        net.LoadParam(p)
+        net.LoadWeights(b)
+        net.FeedInput("data", img)
+        net.Forward()
+        outs[level] = net.Extract("add1_relu")
+        counts[level] = [t for t, _, _ in net.layers()]
+    assert "Eltwise" in counts[0] and "Eltwise" not in counts[2] and "Eltwise" not in counts[3], counts
+    assert nerr(outs[2], outs[0]) <= 1e-5 and np.array_equal(outs[3], outs[2])

@@ -139,7 +139,7 @@ def cpu_baseline(net, procs):
 def net_cpu_baseline(net_name, model, procs, budget=30.0):
     """The REAL reference runtime (feather::Net, AVX2) on this host's cores, SURVEY.md 8(d): the model is loaded once in a helper
     process (oracle/cpu_bench.py: no torch, no HIP), which fork()s P single-thread workers pinned to distinct cores -- the weights are
-    shared copy-on-write -- for P in {1, 16, 64, 128, host cores}; every worker does 1 warm-up + 3 timed forwards of one image.
+    shared copy-on-write -- for P in {1, 8, 16, 32, 64, 128, host cores}; every worker does 1 warm-up + 3 timed forwards of one image.
     Reported: the best aggregate of the sweep with its P, the whole sweep, the one-core figure.  Bounded to ~`budget` seconds."""
     import subprocess
     import tempfile
@@ -176,7 +176,7 @@ def net_cpu_baseline(net_name, model, procs, budget=30.0):
                       f"1 image per process; model loaded once, then P fork()ed single-thread workers pinned to distinct cores (weights shared "
                       f"copy-on-write; the reference's AVX Winograd is single-thread only); {r['warmup']} warm-up + {r['reps']} timed forwards "
                       f"per worker, aggregate = sum of 1 / mean forward time; best of the sweep P = {[s_['procs'] for s_ in r['sweep']]}"
-                      + (f" (P = {r['skipped_for_time']} skipped: time cap {r['budget_s']:.0f}s)" if r["skipped_for_time"] else "")
+                      + (f" (P = {r['skipped']} not run: time cap {r['budget_s']:.0f}s or aggregate already under half of the best)" if r["skipped"] else "")
                       + f"; {r['sweep_s']:.1f}s sweep + {r['load_s']:.1f}s load, {wall:.1f}s wall",
             "sweep": r["sweep"], "single_core_images_per_s": one["images_per_s"] if one else None, "cpu_model": r["cpu_model"],
             "host_cores": r["host_cores"]}

@@ -126,4 +126,106 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
     }
 }
 
+// The same kernel with a 128 x 96 tile, for column counts that 64-column tiles pad badly (round 3).  VGG-16's conv5 layers at batch 32 have
+// P = 9 tiles x 32 images = 288 columns = 4.5 tiles of 64: a ninth of the executed MFMAs multiplied padding (100 TF algorithmic = 111 TF
+// executed).  288 = 3 x 96 exactly, and 4 x 3 x 64 blocks are 3 per CU -- one round, everything resident.  Waves 4 x 1: a wave owns 32
+// rows x 96 columns = three 32x32 accumulators sharing one A fragment (1 A + 3 B LDS reads per 3 MFMAs).  B tile [16][96] is six 1-KB
+// LDS-DMA pieces (lane -> row e / 24, 16-byte column e % 24), A eight; two buffers (28 KB), 5 blocks per CU.
+__global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemmPolicy::Params prm)
+{
+    constexpr int BM = 128, BN = 96, BK = 16, EPI_LD = 36, NBUF = 2;
+    constexpr int BUF_FLOATS = BK * (BM + BN);
+    constexpr int LDSF = NBUF * BUF_FLOATS > 4 * 32 * EPI_LD ? NBUF * BUF_FLOATS : 4 * 32 * EPI_LD;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+
+    const int nwg = prm.batches * prm.m_tiles * prm.n_tiles;
+    int vid = xcd_remap(blockIdx.x, nwg);
+    const int mt = vid % prm.m_tiles;
+    vid /= prm.m_tiles;
+    const int nt = vid % prm.n_tiles;
+    const int xi = vid / prm.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int k_tiles = prm.k_tiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // A: wave w, piece i covers rows 4w + 2i, 4w + 2i + 1 (32 lanes x 16 B per row), as in the 64-column kernel
+    const float* srcA = prm.U + (size_t)xi * prm.Cp * prm.Kp + (size_t)(wave * 4 + half) * prm.Kp + m0 + l31 * 4;
+    const size_t a_step = (size_t)BK * prm.Kp;
+    // B: piece j = wave (and wave + 4 for waves 0, 1) is float4 elements 64 j .. 64 j + 63 of the [16][24 float4] tile
+    const float* srcB = prm.V + (size_t)xi * prm.C * prm.Pp + n0;
+    const int e0 = wave * 64 + lane, e1 = (wave + 4) * 64 + lane;
+    const int b0_row = e0 / 24, b0_col = (e0 - b0_row * 24) * 4, b1_row = e1 / 24, b1_col = (e1 - b1_row * 24) * 4;
+
+    auto issue = [&](int kt, int buf) {
+        float* base = lds + buf * BUF_FLOATS;
+        const float* a = srcA + (size_t)kt * a_step;
+        __builtin_amdgcn_global_load_lds(a, (lds_void*)(base + (wave * 4) * BM), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(a + (size_t)2 * prm.Kp, (lds_void*)(base + (wave * 4 + 2) * BM), 16, 0, 0);
+        float* bb = base + BK * BM;
+        {
+            const int r = min(kt * BK + b0_row, prm.C - 1);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp + b0_col, (lds_void*)(bb + wave * 256), 16, 0, 0);
+        }
+        if (wave < 2)
+        {
+            const int r = min(kt * BK + b1_row, prm.C - 1);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp + b1_col, (lds_void*)(bb + (wave + 4) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int a_off = half * BM + wave * 32 + l31;
+    const int b_off = BK * BM + half * BN + l31;
+    int cur = 0;
+    for (int kt = 0; kt < k_tiles; ++kt)
+    {
+        if (kt + 1 < k_tiles) issue(kt + 1, cur ^ 1);
+        const float* as = lds + cur * BUF_FLOATS + a_off;
+        const float* bs = lds + cur * BUF_FLOATS + b_off;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp)
+        {
+            const float fa = as[(2 * kp) * BM], fb0 = bs[(2 * kp) * BN], fb1 = bs[(2 * kp) * BN + 32], fb2 = bs[(2 * kp) * BN + 64];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb2, acc[2], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+
+    float* const scr = lds + wave * (32 * EPI_LD);
+    const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
+    const int mrow = m0 + wave * 32 + e_row;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+    {
+        float* mbase = prm.M + (size_t)xi * prm.K * prm.Pp + n0 + j * 32 + e_c4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[j][r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * EPI_LD + e_c4]);
+            const int m = mrow + q * 8;
+            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Pp) = v;
+        }
+    }
+}
+
+// does the 96-column tile pad fewer columns than the 64-column one?  (pure function of the column count)
+inline bool wino_gemm_prefers_96(int columns) { return ceil_div(columns, 96) * 96 < ceil_div(columns, 64) * 64; }
+
 } // namespace fhip

@@ -609,7 +609,13 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     {
         g.m_tiles = g.Kp / WinoShapeBig::BM;
         g.n_tiles = ceil_div(pl.columns, WinoShapeBig::BN);
-        if (g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
+        if (g.k_tiles >= 8 && wino_gemm_prefers_96(pl.columns))
+        {
+            // column counts that 64-column tiles pad by a third of a tile or more (VGG-16 conv5 b32: 288 = 3 x 96)
+            g.n_tiles = ceil_div(pl.columns, 96);
+            hipLaunchKernelGGL(wino_gemm_glds96_kernel, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
+        }
+        else if (g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
             hipLaunchKernelGGL(wino_gemm_glds_kernel<2>, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
         else
             hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),

@@ -9,7 +9,8 @@ images/s summed.  This helper
     memory bandwidth on exactly that);
   * sweeps P over an ascending list, each worker doing 1 untimed warm-up + `reps` (>= 3) individually timed forwards
     (clock_gettime inside the shim, like the reference's helper.cpp:89-98);  aggregate(P) = sum over workers of 1 / mean(times);
-  * stops the sweep when the next P would not fit the time budget (predicted from the previous P) and says which were skipped; a worker
+  * stops the sweep when the next P would not fit the time budget (predicted from the previous P), or when the aggregate has fallen
+    under half of the best so far (past the knee more processes only thrash the memory system), and says which were skipped; a worker
     that runs into the deadline stops after the forward it is in (never fewer than one timed forward);
   * prints ONE JSON object on stdout.
 
@@ -81,7 +82,7 @@ def main():
     ap.add_argument("--input", required=True)
     ap.add_argument("--output", required=True)
     ap.add_argument("--shape", default="3,224,224")
-    ap.add_argument("--procs", default="", help="ascending list of process counts (default: 1,16,64,128,<host cores>)")
+    ap.add_argument("--procs", default="", help="ascending list of process counts (default: 1,8,16,32,64,128,<host cores>)")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--budget", type=float, default=30.0, help="seconds for the whole sweep (model load not included)")
     a = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     from oracle import netcheck
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     ncpu = len(cores)
-    plist = [int(v) for v in a.procs.split(",") if v] if a.procs else [1, 16, 64, 128, ncpu]
+    plist = [int(v) for v in a.procs.split(",") if v] if a.procs else [1, 8, 16, 32, 64, 128, ncpu]
     plist = sorted({min(p, ncpu) for p in plist if p >= 1})
     reps = max(3, a.reps)
     shape = tuple(int(v) for v in a.shape.split(","))
@@ -117,6 +118,10 @@ def main():
                       "best_forward_s": round(min(min(t) for t in times), 4), "timed_forwards_per_worker": min(len(t) for t in times),
                       "wall_s": round(wall, 2)})
         prev = (p, wall)
+        if sweep[-1]["images_per_s"] < 0.5 * max(r["images_per_s"] for r in sweep):
+            # past the knee: more processes only thrash the memory system (each forward streams the whole model and its activations)
+            skipped += [q for q in plist if q > p]
+            break
     ref.close()
     model = ""
     try:
@@ -127,7 +132,7 @@ def main():
     except OSError:
         pass
     best = max(sweep, key=lambda r: r["images_per_s"]) if sweep else None
-    json.dump({"sweep": sweep, "skipped_for_time": skipped, "best": best, "reps": reps, "warmup": 1, "host_cores": ncpu, "cpu_model": model,
+    json.dump({"sweep": sweep, "skipped": skipped, "best": best, "reps": reps, "warmup": 1, "host_cores": ncpu, "cpu_model": model,
                "load_s": round(load_s, 2), "sweep_s": round(time.perf_counter() - t_start, 2), "budget_s": a.budget}, sys.stdout)
     sys.stdout.write("\n")
 

@@ -58,6 +58,9 @@ WINO = [
     (conv_geom(64, 64, 224, 3, 1, 1), 1),          # VGG conv1_2 (1444 tiles)
     (conv_geom(24, 36, 12, 3, 1, 0), 2),           # no padding, C % 16 != 0 (not 20: the reference crashes on C % 8 == 4 with ragged tiles)
     (conv_geom(12, 8, 20, 3, 1, 2), 2),            # pad 2 (wider than the kernel needs)
+    (conv_geom(128, 128, 14, 3, 1, 1), 10),        # P = 90 columns: the 128 x 96 LDS-DMA tile (one column tile, 6 padding columns)
+    (conv_geom(256, 192, 14, 3, 1, 1), 32),        # P = 288 = 3 x 96 (VGG conv5's column count), K = 1.5 row tiles
+    (conv_geom(160, 144, 20, 3, 1, 1), 5),         # P = 80, C = 160 (10 k-tiles), K = 144: 96-column tile with ragged rows
 ]
 
 

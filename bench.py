@@ -416,6 +416,7 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     prob = net.Extract(out_name)
     if not np.isfinite(prob).all() or abs(float(prob[0].sum()) - 1.0) > 1e-3:
         raise SystemExit(f"bench: {net_name}: the net's output is not a probability vector")
+    sustained_mfma()  # the device's pure-MFMA ceiling (reported next to every MFMA roofline) is measured BEFORE the timed region, once per process
     dt = timed_region(net.Forward, steps, warmup, env)
     total_images = global_batch if global_batch else world * nb
     res = {"net": net_name, "images_per_s": round(total_images * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,

@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (strong scaling, SURVEY.md 8d config 5: "
                     "--net resnet50 --global-batch 512 --gpus 8); rank r takes shard_range(global, r, N) images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the 200-step steady-state cross-check region (profiling runs: every extra step is traced)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay per step")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: one per host core, bounded by free memory)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
@@ -633,13 +634,13 @@ def main():
         model, extras = None, {}
     else:
         # ---- headline: BASELINE.json configs[1] (VGG-16, 32 images per GPU) unless --net says otherwise; weak scaling at N > 1
-        head, model = measure_net(head_net, a, env, a.steps, a.warmup, a.global_batch, a.batch, steady=STEADY_STEPS)
+        head, model = measure_net(head_net, a, env, a.steps, a.warmup, a.global_batch, a.batch, steady=0 if a.no_steady else STEADY_STEPS)
         extras = {}
         if not explicit and not a.headline_only:
             # ---- the other nets BASELINE.json's metric names, same process, same timing procedure
             if world == 1:
                 for name in ("resnet50", "mobilenet_v1"):  # not the contract's headline: never fewer than 100 timed steps
-                    extras[name], _ = measure_net(name, a, env, max(a.steps, 100), a.warmup, steady=STEADY_STEPS)
+                    extras[name], _ = measure_net(name, a, env, max(a.steps, 100), a.warmup, steady=0 if a.no_steady else STEADY_STEPS)
                 # the one-GPU point of configs[4]'s strong-scaling curve (ResNet-50, 512 images in total)
                 extras["resnet50_global512"], _ = measure_net("resnet50", a, env, max(a.steps // 5, 5), max(a.warmup // 2, 1), global_batch=512,
                                                               detail=False)

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --no-cpu-baseline --no-steady $*"
 echo "== kernel trace + stats: $CMD"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 tail -2 $OUT/trace.log

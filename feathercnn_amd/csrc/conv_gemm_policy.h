@@ -302,9 +302,17 @@ struct ConvGemmPolicy
         }
         __device__ void put4(const Params& p, int m, float4 v) const
         {
-            put4b(p, m, v, (p.has_bias && !part && m < p.K) ? p.bias[m] : 0.f);
+            put4b(p, m, v, (p.has_bias && !part && m < p.K) ? p.bias[m] : 0.f, residual4(p, m));
         }
-        __device__ void put4b(const Params& p, int m, float4 v, float b) const
+        // the residual operand of this row's 4 columns where they are one aligned 16-byte piece (the ResNet shapes); the ragged case is
+        // read element by element in put4b
+        __device__ float4 residual4(const Params& p, int m) const
+        {
+            if (p.has_residual && wide && !part && m < p.K)
+                return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr[0] + (size_t)m * p.OHW) + p.residual_delta);
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __device__ void put4b(const Params& p, int m, float4 v, float b, float4 r) const
         {
             if (m >= p.K) return;
             if (part)
@@ -331,7 +339,6 @@ struct ConvGemmPolicy
                 auto res = [&](const float* o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(o) + p.residual_delta); };
                 if (wide)
                 {
-                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr[0] + moff) + p.residual_delta);
                     v.x += r.x;
                     v.y += r.y;
                     v.z += r.z;

@@ -356,6 +356,43 @@ __global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kern
         if (chunk + (int)gridDim.x < chunks) FHIP_DW_REQUEST(chunk + (int)gridDim.x)
         const int nout = np * OHW;
         float* const obase = q.out + (size_t)plane0 * OHW; // 16-byte aligned
+        if constexpr (HH == 7 && S == 1)
+        {
+            // 7 x 7 planes (49 floats: groups of four outputs straddle rows AND planes).  A lane owns one whole image row: 3 x 7 LDS
+            // dwords, column validity known at compile time, the 7 results go to a second LDS image and leave as 16-byte stores.
+            float* const otile = bl + chunk_planes; // [chunk_planes][49]
+            for (int it = tid; it < np * 7; it += 256)
+            {
+                const int pl = it / 7, y = it - pl * 7;
+                const float4* w4 = reinterpret_cast<const float4*>(wl + pl * 12);
+                const float4 wa = w4[0], wb = w4[1], wc = w4[2];
+                const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
+                const float bias = bl[pl];
+                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                {
+                    const int yy = y + m - 1;
+                    const bool rowok = (unsigned)yy < 7u;
+                    const float* row = tile + pl * 49 + min(max(yy, 0), 6) * 7;
+                    float r[7];
+#pragma unroll
+                    for (int x = 0; x < 7; ++x) r[x] = rowok ? row[x] : 0.f;
+#pragma unroll
+                    for (int x = 0; x < 7; ++x)
+#pragma unroll
+                        for (int n = 0; n < 3; ++n)
+                            if (x + n - 1 >= 0 && x + n - 1 < 7) acc[x] += r[x + n - 1] * w[m * 3 + n];
+                }
+#pragma unroll
+                for (int x = 0; x < 7; ++x) otile[it * 7 + x] = apply_act(acc[x] + bias, q.relu);
+            }
+            __syncthreads();
+            const int n4o = nout >> 2;
+            for (int i = tid; i < n4o; i += 256) reinterpret_cast<f32x4*>(obase)[i] = reinterpret_cast<const f32x4*>(otile)[i];
+            for (int i = (n4o << 2) + tid; i < nout; i += 256) obase[i] = otile[i];
+        }
+        else
         for (int o0 = tid * 4; o0 < nout; o0 += 1024)
         {
             float res[4];
@@ -432,11 +469,94 @@ __global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kern
 #undef FHIP_DW_REQUEST
 }
 
+// The same idea for LARGE planes whose rows are whole float4 (W % 4 == 0: 112, 56): a block owns a BAND of RB output rows of one plane.
+// The RB + 2 input rows it needs are one contiguous run of the tensor (coalesced 16-byte loads, the two halo rows are re-read by the
+// neighbouring bands through L2), four consecutive outputs of a row per lane (a group never wraps: rows are whole float4), three 6-float
+// LDS runs for 36 FMAs, one 16-byte store.  Stride 1, pad 1 on every side.  WW and RB are compile-time: no division by a variable.
+template <int WW, int RB, int UNR>
+__global__ __launch_bounds__(256) void depthwise3x3_band_kernel(const DwParams q, int bands_per_plane)
+{
+    constexpr int ROWS = RB + 2, W4 = WW / 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 + ROWS * WW + 4];
+    float* const tile = smem + 4; // row r of the image = input row y0 - 1 + r
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x / bands_per_plane, band = blockIdx.x - plane * bands_per_plane;
+    const int y0 = band * RB, c = plane % q.C;
+    const int ya = max(y0 - 1, 0), yb = min(y0 + RB + 1, q.H); // input rows [ya, yb) exist
+    const f32x4* src = reinterpret_cast<const f32x4*>(q.in + (size_t)plane * q.H * WW + (size_t)ya * WW);
+    const int n4 = (yb - ya) * W4;
+    f32x4 v[UNR];
+#pragma unroll
+    for (int b = 0; b < UNR; ++b) v[b] = src[min(tid + b * 256, n4 - 1)];
+    // taps and bias: wave-uniform scalar loads
+    const float4* w4 = reinterpret_cast<const float4*>(q.w12 + (size_t)c * 12);
+    const float4 wa = w4[0], wb = w4[1], wc = w4[2];
+    const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
+    const float bias = q.has_bias ? q.bias[c] : 0.f;
+    f32x4* dst = reinterpret_cast<f32x4*>(tile + (ya - (y0 - 1)) * WW);
+#pragma unroll
+    for (int b = 0; b < UNR; ++b)
+        if (tid + b * 256 < n4) dst[tid + b * 256] = v[b];
+    __syncthreads();
+    const int rows_out = min(RB, q.OH - y0);
+    float* const obase = q.out + (size_t)plane * q.OH * WW + (size_t)y0 * WW;
+    for (int g = tid; g < rows_out * W4; g += 256)
+    {
+        const int ly = g / W4, x0 = (g - ly * W4) * 4;
+        float t[3][6];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[m][j] = tile[(ly + m) * WW + x0 - 1 + j];
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+            {
+                const bool rowok = (unsigned)(y0 + ly + m - 1) < (unsigned)q.H;
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+                {
+                    const bool ok = rowok && (unsigned)(x0 + e + n - 1) < (unsigned)WW;
+                    acc += (ok ? t[m][e + n] : 0.f) * w[m * 3 + n];
+                }
+            }
+            res[e] = apply_act(acc + bias, q.relu);
+        }
+        *reinterpret_cast<float4*>(obase + (size_t)ly * WW + x0) = make_float4(res[0], res[1], res[2], res[3]);
+    }
+}
+
+// does the band kernel take this geometry?  3x3, stride 1, pad 1 on every side, square planes of 112 or 56 pixels
+static inline bool dw_band_applicable(const DwParams& q, int pad_right, int pad_bottom)
+{
+    return q.KH == 3 && q.KW == 3 && q.SH == 1 && q.SW == 1 && q.PL == 1 && q.PT == 1 && pad_right == 1 && pad_bottom == 1 && q.H == q.W &&
+           (q.H == 112 || q.H == 56);
+}
+
+static inline void dw_band_launch(const DwParams& q, hipStream_t s)
+{
+    if (q.H == 112)
+    {
+        // 16-row bands: 18 x 112 floats = 504 float4 (2 requests per lane), 7 bands per plane
+        hipLaunchKernelGGL((depthwise3x3_band_kernel<112, 16, 2>), dim3((unsigned)q.planes * 7u), dim3(256), 0, s, q, 7);
+    }
+    else
+    {
+        // 56 x 56: 28-row bands: 30 x 56 floats = 420 float4, 2 bands per plane
+        hipLaunchKernelGGL((depthwise3x3_band_kernel<56, 28, 2>), dim3((unsigned)q.planes * 2u), dim3(256), 0, s, q, 2);
+    }
+}
+
 // LDS bytes of the flat kernel for a chunk of `cp` planes of HH x HH
-static inline size_t dw_flat_lds_bytes(int hh, int cp)
+static inline size_t dw_flat_lds_bytes(int hh, int cp, int stride = 0)
 {
     const int pad = (hh + 1 + 3) / 4 * 4;
-    return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13) * sizeof(float);
+    // 7 x 7 stride 1: a second image for the results (cp * 13 floats of taps + bias is a multiple of 4 floats when cp % 4 == 0)
+    return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13 + ((hh == 7 && stride == 1) ? cp * 49 : 0)) * sizeof(float);
 }
 
 // does the flat kernel take this geometry?  3x3, pad 1 on every side, stride 1 / 2, square planes of 7, 14 or 28 pixels
@@ -451,7 +571,7 @@ static inline void dw_flat_launch(const DwParams& q, int cp, int grid, hipStream
 {
     const int chunks = ceil_div(q.planes, cp);
     const int unr = ceil_div(cp * q.H * q.W / 4, 256);
-    const size_t lds = dw_flat_lds_bytes(q.H, cp);
+    const size_t lds = dw_flat_lds_bytes(q.H, cp, q.SH);
     grid = std::min(grid, chunks);
 #define FHIP_FLAT_U(H_, S_, U_) hipLaunchKernelGGL((depthwise3x3_flat_kernel<H_, S_, U_>), dim3(grid), dim3(256), lds, s, q, cp, chunks)
 #define FHIP_FLAT(H_, S_)                        \
@@ -640,11 +760,13 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     // (tools/dw_bench.hip, b256): 28 px s1 73 us vs 107 us for the direct kernel, s2 50 vs 67; 14 px s1 40 vs 70, s2 26 vs 34 (chunk
     // kernel).  One chunk per block: persistent blocks with the next chunk prefetched were slower at every grid size.  7 x 7 planes stay
     // on the direct kernel (34 vs 39 us cache-resident, which is how the net finds them).
-    if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && q.H != 7)
+    if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && (q.H != 7 || q.SH == 1))
     {
-        const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : (q.SH == 1 ? 15 : 20);
+        const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : q.H == 14 ? (q.SH == 1 ? 15 : 20) : 36; // 7 x 7: 36 planes = 252 row items
         dw_flat_launch(q, cp, 0x7fffffff, s);
     }
+    else if (dw_band_applicable(q, p.pad_right, p.pad_bottom))
+        dw_band_launch(q, s);
     else if (small_plane)
     {
         // ~3136 floats (12.25 KB) of planes per block: 4 x 28^2, 16 x 14^2, 64 x 7^2; a multiple of 4 planes keeps every chunk

@@ -76,7 +76,8 @@ struct GemmShape
 //       (m4 / n4 = first of the 4 consecutive rows / columns this thread always fetches; loads are unconditional
 //        from clamped addresses, `ok` bit e = element e is real data, zero-fill happens at LDS-write time)
 //   struct Store { Store(const Params&, int batch, int n4); void put4(const Params&, int m, float4 v) const;
-//                  void put4b(const Params&, int m, float4 v, float bias_m) const; }   (put4b: the bias value comes from the caller)
+//                  float4 residual4(const Params&, int m) const;   (the fused residual operand of row m's 4 columns, requested early; zeros if none)
+//                  void put4b(const Params&, int m, float4 v, float bias_m, float4 res) const; }   (bias and residual come from the caller)
 //   static float bias_at(const Params&, int m);   bias of output row m (0 when there is none / the row does not exist)
 //       (4 consecutive output columns n4..n4+3 of row m)
 //   static int k_count(const Params&, int batch);   k-tiles this batch entry reduces over (the loaders know where they start)
@@ -242,11 +243,16 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
 #pragma unroll
             for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * Shape::EPI_LD + l31] = acc[i][j][r];
             const int mbase = m0 + wm * Shape::WTM + i * 32 + e_row;
+            // the fused residual operand of the four stores below is requested here, so its round trips overlap each other and the LDS
+            // transpose instead of sitting one by one in front of every store (zeros when the layer has none)
+            float4 res[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[q] = st.residual4(prm, mbase + q * 8);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
             {
                 const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * Shape::EPI_LD + e_c4]);
-                st.put4b(prm, mbase + q * 8, v, bias_r[i][q]);
+                st.put4b(prm, mbase + q * 8, v, bias_r[i][q], res[q]);
             }
         }
     }

@@ -52,7 +52,8 @@ struct WinoGemmPolicy
         {
             if (m < p.K) *reinterpret_cast<float4*>(base + (size_t)m * p.Pp) = v; // Pp is a multiple of the column tile
         }
-        __device__ void put4b(const Params& p, int m, float4 v, float) const { put4(p, m, v); }
+        __device__ float4 residual4(const Params&, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+        __device__ void put4b(const Params& p, int m, float4 v, float, float4) const { put4(p, m, v); }
     };
 };
 

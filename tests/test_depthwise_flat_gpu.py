@@ -26,6 +26,16 @@ FLAT = [
     (conv_geom(13, 13, 28, 3, 1, 1, group=13), 7),       # 91 planes: tail of 3 (stride 1, chunks of 4)
     (conv_geom(13, 13, 28, 3, 2, 1, group=13), 7),       # tail of 1 (chunks of 5)
     (conv_geom(1, 1, 14, 3, 1, 1, group=1), 1),          # one plane (the reference routes group == C == 1 to DEPTHWISE)
+    # 7 x 7 stride 1 (row-per-lane path of the flat kernel, chunks of 36 planes)
+    (conv_geom(1024, 1024, 7, 3, 1, 1, group=1024), 2),  # MobileNet conv14 shape
+    (conv_geom(37, 37, 7, 3, 1, 1, group=37), 5),        # 185 planes: 5 chunks + 5 planes, odd channel count
+    (conv_geom(1, 1, 7, 3, 1, 1, group=1), 1),           # one plane: 49 floats = 12 float4 + 1
+    (conv_geom(3, 3, 7, 3, 1, 1, group=3), 1),           # 147 floats: ragged tail of the float4 copies
+    # band kernel: 112- and 56-pixel planes, stride 1 (16- / 28-row bands)
+    (conv_geom(32, 32, 112, 3, 1, 1, group=32), 2),      # MobileNet conv2_dw shape
+    (conv_geom(5, 5, 112, 3, 1, 1, group=5), 3),
+    (conv_geom(128, 128, 56, 3, 1, 1, group=128), 2),    # conv4_dw shape
+    (conv_geom(9, 9, 56, 3, 1, 1, group=9), 1),
 ]
 
 
@@ -35,13 +45,15 @@ def test_flat_route_matches_oracle(g, batch, cuda, checker, port):
 
 
 @pytest.mark.parametrize("bias,act", [(0, 0), (1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("h,s", [(14, 1), (14, 2), (28, 1), (28, 2)])
+@pytest.mark.parametrize("h,s", [(14, 1), (14, 2), (28, 1), (28, 2), (7, 1), (56, 1), (112, 1)])
 def test_flat_route_epilogues(h, s, bias, act, cuda, checker, port):
     check(conv_geom(24, 24, h, 3, s, 1, group=24, bias=bias, act=act), 3, cuda, checker, port, seed=5)
 
 
 NEIGHBOURS = [
-    conv_geom(24, 24, 7, 3, 1, 1, group=24),                    # 7 x 7: direct kernel
+    conv_geom(24, 24, 7, 3, 2, 1, group=24),                    # 7 x 7 stride 2
+    Geom(24, 24, 56, 56, 3, 3, 1, 1, 1, 0, 1, 0, 24, 1, 1),     # 56 x 56, pad 1 0 1 0
+    Geom(8, 8, 112, 56, 3, 3, 1, 1, 1, 1, 1, 1, 8, 1, 1),       # 112 x 56, not square
     Geom(24, 24, 14, 28, 3, 3, 1, 1, 1, 1, 1, 1, 24, 1, 1),     # 14 x 28, not square
     Geom(24, 24, 14, 14, 3, 3, 1, 1, 1, 0, 1, 0, 24, 1, 1),     # pad_right = pad_bottom = 0
     Geom(24, 24, 28, 28, 3, 3, 2, 2, 1, 0, 1, 0, 24, 1, 1),     # stride 2, pad 1 0 1 0 (TensorFlow-style SAME)

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
             {
                 const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * Shape::EPI_LD + e_c4]);
                 if (TUNE & 2)
-                    st.put4b(prm, mbase + q * 8, v, bias_r[i][q]);
+                    st.put4b(prm, mbase + q * 8, v, bias_r[i][q], st.residual4(prm, mbase + q * 8));
                 else
                     st.put4(prm, mbase + q * 8, v);
                 if (j == 0 && i == 0) stamp(); // [10..13] after each store of the first 32x32 piece

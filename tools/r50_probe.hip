@@ -74,8 +74,8 @@ struct Case
     int C, K, H, S, N;
 };
 
-template <class Shape, int MODE, int ABL>
-static void launch_core(const fhip_conv_param& p, int batch, const float* packed, const float* in, float* out, const float* bias)
+template <class Shape, int MODE, int ABL, bool PRODUCT = false>
+static void launch_core(const fhip_conv_param& p, int batch, const float* packed, const float* in, float* out, const float* bias, const float* residual = nullptr)
 {
     ConvGemmParams g;
     memset(&g, 0, sizeof g);
@@ -103,10 +103,15 @@ static void launch_core(const fhip_conv_param& p, int batch, const float* packed
     g.has_bias = 1;
     g.relu = 1;
     g.split_k = 1;
+    g.has_residual = residual != nullptr;
+    g.residual_delta = residual ? reinterpret_cast<const char*>(residual) - reinterpret_cast<const char*>(out) : 0;
     g.k_tiles = g.Kdp / 16;
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = (g.Ntot + Shape::BN - 1) / Shape::BN;
-    hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, ConvGemmPolicy<MODE>, ABL, 3>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
+    if (PRODUCT)  // the library's kernel (residual operand requested ahead of the LDS transpose) instead of the instrumented copy (per-store request)
+        hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
+    else
+        hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, ConvGemmPolicy<MODE>, ABL, 3>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
 }
 
 static double pct(std::vector<double> v, double q)
@@ -183,6 +188,27 @@ int main(int argc, char** argv)
             }
         };
         const double t_core = time_us([&] { core(false); }, reps);
+        if (getenv("PROBE_RESIDUAL") && !small && vec)
+        {
+            // the fused residual add (ResNet's expand layers): residual operand requested per store (the instrumented copy = the round-2 epilogue)
+            // against requested ahead of the LDS transpose (the library's kernel); interleaved rounds, median of 7
+            float* res = nullptr;
+            CK(hipMalloc(&res, out_n * 4));
+            fill_random(res, std::min<size_t>(out_n, 1 << 24), 5, 1.f);
+            using Sh = GemmShape<128, 64, 16, 2, 2, 4>;
+            std::vector<double> ta, tb, tc;
+            for (int r = 0; r < 7; ++r)
+            {
+                ta.push_back(time_us([&] { launch_core<Sh, 2, 0, false>(p, cs.N, packed, in, out, bias, res); }, reps));
+                tb.push_back(time_us([&] { launch_core<Sh, 2, 0, true>(p, cs.N, packed, in, out, bias, res); }, reps));
+                tc.push_back(time_us([&] { launch_core<Sh, 2, 0, true>(p, cs.N, packed, in, out, bias, nullptr); }, reps));
+            }
+            std::sort(ta.begin(), ta.end());
+            std::sort(tb.begin(), tb.end());
+            std::sort(tc.begin(), tc.end());
+            printf("      residual add fused: per-store request %.1f us, requested ahead %.1f us; without residual %.1f us\n", ta[3], tb[3], tc[3]);
+            (void)hipFree(res);
+        }
         if (getenv("PROBE_SHAPES"))
         {
             // tile-shape scan on this layer: same main loop, same packed weights (a tile never crosses a 64- / 128-row weight panel);

@@ -5,9 +5,11 @@
 // in fp32, + bias[c], ReLU, floor output dims -- but no padded copy of the input: padding is a bounds check.
 //
 // This is an HBM-bound kernel (9 FMA per 8 bytes moved): the whole job is to move each input and output element once.
-// Four forms live here, chosen by shape (measurements in DESIGN.md 3.3):
-//   * depthwise3x3_flat_kernel    -- 3x3, stride 1/2, pad 1, 14 x 14 and 28 x 28 planes: a chunk of whole planes staged in LDS with
-//     coalesced 16-byte loads, four consecutive outputs of the flat output stream per lane (round 3).
+// Five forms live here, chosen by shape (measurements in DESIGN.md 3.3):
+//   * depthwise3x3_flat_kernel    -- 3x3, stride 1/2, pad 1, 7 x 7 / 14 x 14 / 28 x 28 planes: a chunk of whole planes staged in LDS with
+//     coalesced 16-byte loads, four consecutive outputs of the flat output stream per lane (7 x 7: one image row per lane) (round 3).
+//   * depthwise3x3_band_kernel    -- 3x3, stride 1, pad 1, 112- and 56-pixel planes: a band of output rows of one plane per block, its
+//     input rows staged in LDS the same way (round 3).
 //   * depthwise3x3_direct_kernel  -- 3x3, stride 1/2, pad_left 1 (the MobileNet shapes).  NO LDS: every lane produces
 //     a VX-wide x R-high output patch straight from global memory with aligned vector loads, takes its two halo taps
 //     per row from the neighbouring lanes (cross-lane moves, not loads), and stores R vectors.
@@ -567,8 +569,9 @@ static inline bool dw_flat_applicable(const DwParams& q, int pad_right, int pad_
 }
 
 // launch the flat kernel on `grid` persistent blocks with chunks of `cp` planes (cp * H*W % 4 == 0, cp <= 85, cp * H*W <= 6 * 1024)
-static inline void dw_flat_launch(const DwParams& q, int cp, int grid, hipStream_t s)
+static inline void dw_flat_launch(const DwParams& q, int cp, int grid, hipStream_t s) // cp % 4 == 0 for 7 x 7 planes
 {
+    cp = std::min(cp, 84); // a block's taps are requested by lanes 0 .. 3 * cp - 1 (one float4 each)
     const int chunks = ceil_div(q.planes, cp);
     const int unr = ceil_div(cp * q.H * q.W / 4, 256);
     const size_t lds = dw_flat_lds_bytes(q.H, cp, q.SH);
@@ -758,8 +761,10 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     // 14 x 14 and 28 x 28 planes, pad 1 all round (MobileNet-V1's conv6 ... conv13, 63 % of the depthwise bytes that stay depthwise
     // launches in the fused net): the flat kernel.  Chunk sizes measured on MI355X, tensors NOT resident in the memory-side cache
     // (tools/dw_bench.hip, b256): 28 px s1 73 us vs 107 us for the direct kernel, s2 50 vs 67; 14 px s1 40 vs 70, s2 26 vs 34 (chunk
-    // kernel).  One chunk per block: persistent blocks with the next chunk prefetched were slower at every grid size.  7 x 7 planes stay
-    // on the direct kernel (34 vs 39 us cache-resident, which is how the net finds them).
+    // kernel).  One chunk per block: persistent blocks with the next chunk prefetched were slower at every grid size.  7 x 7 stride 1
+    // (conv14) takes the flat kernel's row-per-lane path: 23 us vs 49 us for the direct kernel (18 vs 37 cache-resident).
+    // 112- and 56-pixel planes at stride 1 (conv2, and conv4 when it is not fused into its 1x1 layer): the band kernel, 144 vs 165 us
+    // and 147 vs 181 us.
     if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && (q.H != 7 || q.SH == 1))
     {
         const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : q.H == 14 ? (q.SH == 1 ? 15 : 20) : 36; // 7 x 7: 36 planes = 252 row items

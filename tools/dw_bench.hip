@@ -186,7 +186,7 @@ int main(int argc, char** argv)
         if (cs.H == 7 || cs.H == 14 || cs.H == 28)
         {
             // chunk sizes whose float4 count is just under a multiple of 256 lanes
-            const std::vector<int> cps = cs.H == 28 ? std::vector<int>{4, 5, 6} : cs.H == 14 ? std::vector<int>{10, 15, 20, 26} : std::vector<int>{36, 72, 108};
+            const std::vector<int> cps = cs.H == 28 ? std::vector<int>{4, 5, 6} : cs.H == 14 ? std::vector<int>{10, 15, 20, 26} : std::vector<int>{36, 72};
             for (int cp : cps)
                 for (int grid : {256 * 4, 256 * 8, 1 << 30})
                 {

@@ -324,7 +324,7 @@ def attribute(net, reps):
         r["frac_of_tighter_bound"] = round(pw_bound_ms / pw_ms, 4)
         roofs.append(r)
     if dw_bytes and stage.get("depthwise"):
-        roofs.append(roofline_hbm("depthwise: depthwise3x3_flat_kernel (14 / 28-pixel planes) / depthwise3x3_direct_kernel", dw_bytes, stage["depthwise"], "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C "
+        roofs.append(roofline_hbm("depthwise: depthwise3x3_flat_kernel (7 / 14 / 28-pixel planes) / depthwise3x3_band_kernel (112 / 56 pixels, stride 1) / depthwise3x3_direct_kernel", dw_bytes, stage["depthwise"], "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C "
                                   "summed over the depthwise launches of a step (the layers fused into their 1x1 convolution have none) / sum of "
                                   "their HIP-event durations on the launch stream"))
     if fz_ms:
@@ -568,7 +568,7 @@ def setup_convstack(a, env):
         if gemm_flops and gemm_ms:
             roofs.append(roofline_mfma("Winograd tile GEMM", gemm_flops, gemm_ms, "2*64*K*C*T*N over the Winograd layers / their tile-GEMM event durations"))
         if dw_bytes and dw_ms:
-            roofs.append(roofline_hbm("depthwise: depthwise3x3_flat_kernel (14 / 28-pixel planes) / depthwise3x3_direct_kernel", dw_bytes, dw_ms, "4*(C*Hin*Win + C*Ho*Wo)*N + 40*C over the depthwise layers / their event durations"))
+            roofs.append(roofline_hbm("depthwise: depthwise3x3_flat_kernel (7 / 14 / 28-pixel planes) / depthwise3x3_band_kernel (112 / 56 pixels, stride 1) / depthwise3x3_direct_kernel", dw_bytes, dw_ms, "4*(C*Hin*Win + C*Ho*Wo)*N + 40*C over the depthwise layers / their event durations"))
         res["rooflines"] = roofs
         res["roofline"] = (roofs[1] if a.net == "mobilenet_v1" and len(roofs) > 1 else roofs[0]) if roofs else None
         res["conv_gflops_per_s_direct"] = round(flops_direct_total * world / (ms_per_step * 1e6), 1)

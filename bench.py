@@ -219,7 +219,43 @@ def roofline_hbm(kernel, nbytes, ms, note):
             "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "work_per_step": nbytes, "ms_per_step": round(ms, 4), "note": note}
 
 
-TRAFFIC_NOTE = ("traffic (HBM bytes from rocprofv3 PMC passes) cannot be collected inside this process; the per-round counters of "
+# kernels behind each roofline row, as rocprofv3 names them (profiles/<round>_<net>/traffic.json keys)
+TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1>", "ConvGemmPolicy<2>", "stream_gemm_kernel"),
+                   "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3>", "ConvGemmPolicy<4>"),
+                   "wino_input_transform_kernel": ("wino_input_transform_kernel",), "wino_chain_kernel": ("wino_chain_kernel",)}
+
+
+def attach_traffic(net_name, roofs):
+    """roofline.traffic: HBM bytes per launch of the row's kernels from the rocprofv3 PMC passes of THIS command (2 * FETCH_SIZE + WRITE_SIZE,
+    separate --pmc passes, the gfx950 correction of MI355X_MICROARCH.md; tools/profile.sh + tools/summarize_prof.py).  PMC counters cannot be
+    read inside the benchmark process, so the figure comes from the digest committed under profiles/ (newest round that has one for this net);
+    null when there is none.  Launch-weighted mean over the kernels of the row; `achieved` and `frac` stay live measurements."""
+    import glob
+    # newest round first; within a round the single-stream profile (what the per-kernel attribution runs) before the replica one
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{net_name}", "traffic.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", f"r*_{net_name}_single_stream", "traffic.json")),
+                   key=lambda q: (os.path.basename(os.path.dirname(q))[:3], q.endswith("_single_stream/traffic.json")))
+    if not cands:
+        return
+    path = cands[-1]
+    try:
+        dig = json.load(open(path))
+    except (OSError, ValueError):
+        return
+    for r in roofs:
+        pats = next((v for k, v in TRAFFIC_KERNELS.items() if r["kernel"].startswith(k)), None)
+        if not pats:
+            continue
+        rows = [v for k, v in dig.items() if any(q in k for q in pats)]
+        n = sum(v["launches_profiled"] for v in rows)
+        if n:
+            r["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in rows) / n)
+            r["traffic_unit"] = "HBM bytes per launch (launch-weighted mean over the row's kernels)"
+            r["traffic_source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2*FETCH + WRITE)"
+
+
+TRAFFIC_NOTE = ("traffic (HBM bytes per launch from rocprofv3 PMC passes) cannot be collected inside this process: it is read from the digest of "
+                "the same command committed under profiles/ (traffic_source); the per-round counters of "
                 "this same command are committed under profiles/ (tools/profile.sh)")
 
 
@@ -439,6 +475,7 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
             net.Forward()
             torch.cuda.synchronize()
         att = attribute(net, max(3, min(steps, 5)))
+        attach_traffic(net_name, att["rooflines"])
         n_model_layers = len(netcheck_layers(p))
         res["workload"] = (f"{net_name} whole net ({n_model_layers} layers in the model file, {len(net.layers())} after fusion level {a.fusion}), "
                            f"batch {nb} per GPU" + (f" as {replicas} concurrent sub-batch replicas of the net (fhip_net_set_sub_batches)" if replicas > 1 else "")

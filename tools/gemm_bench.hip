@@ -58,6 +58,11 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     g.k_tiles = g.Cp / Shape::BK;
     g.n_tiles = g.Pp / Shape::BN;
     g.m_tiles = g.Kp / Shape::BM;
+    if (V0 == 7)
+    {
+        g.n_tiles = (cs.P + 95) / 96;
+        g.Pp = std::max(g.Pp, g.n_tiles * 96);
+    }
     const int tiles = g.batches * g.m_tiles * g.n_tiles;
     dim3 grid(tiles);
     auto launch = [&]() {
@@ -69,6 +74,8 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 6)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 3>), grid, dim3(256), 0, 0, g);
+        else if constexpr (V0 == 7)
+            hipLaunchKernelGGL(wino_gemm_glds96_kernel, grid, dim3(256), 0, 0, g);
         else
             hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
     };
@@ -131,8 +138,8 @@ int main(int argc, char** argv)
     for (auto& c : cases)
     {
         maxU = std::max(maxU, (size_t)64 * round_up(c.C, 32) * round_up(c.K, 256));
-        maxV = std::max(maxV, (size_t)64 * c.C * round_up(c.P, 256));
-        maxM = std::max(maxM, (size_t)64 * c.K * round_up(c.P, 256));
+        maxV = std::max(maxV, (size_t)64 * c.C * round_up(c.P, 384));
+        maxM = std::max(maxM, (size_t)64 * c.K * round_up(c.P, 384));
     }
     float *U, *V, *M;
     CK(hipMalloc(&U, maxU * 4));
@@ -165,6 +172,16 @@ int main(int argc, char** argv)
     {
         if (getenv("GEMM_ONE") && !(c.C == 512 && c.K == 512 && c.P == 800)) continue;
         printf("case C=%d K=%d P=%d\n", c.C, c.K, c.P);
+        if (getenv("GEMM_96"))
+        {
+            if (c.C < 128) continue;
+            for (int round = 0; round < 5; ++round)
+            {
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>("128x64 glds (product)", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 7>("128x96 glds", c, U, V, M, reps);
+            }
+            continue;
+        }
         for (int round = 0; round < 3; ++round)
         {
             run<GemmShape<128, 64, 16, 2, 2, 4>, 0>("128x64x16 2x2 (product)", c, U, V, M, reps);

@@ -770,7 +770,7 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
         const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : q.H == 14 ? (q.SH == 1 ? 15 : 20) : 36; // 7 x 7: 36 planes = 252 row items
         dw_flat_launch(q, cp, 0x7fffffff, s);
     }
-    else if (dw_band_applicable(q, p.pad_right, p.pad_bottom))
+    else if (dw_band_applicable(q, p.pad_right, p.pad_bottom) && planes * 7 <= 0x7fffffffLL)
         dw_band_launch(q, s);
     else if (small_plane)
     {

@@ -15,6 +15,7 @@
 #include "gemm_core.h"
 #include "conv_gemm_policy.h"
 #include "stream_gemm.h"
+#include "ip_stream.h"
 
 namespace fhip
 {
@@ -48,13 +49,37 @@ static bool stream_profitable(const fhip_conv_param& p, int batch)
     return stream_eligible(p) && p.input_channels >= 256 && p.output_channels >= 128 && p.output_channels <= 512 &&
            (long long)batch * p.output_h * p.output_w >= 4096;
 }
+// ---- the weight-streaming InnerProduct route (ip_stream.h) -----------------------------------------------------------------------
+// eligible: a 1x1 convolution over a 1x1 image (what feather::InnerProductLayer is on the device) -- decides the packed size;
+// profitable: at most one MFMA column tile of images and a weight matrix worth streaming (VGG-16's fc6 / fc7 / fc8 at batch <= 32).
+static bool ip_eligible(const fhip_conv_param& p)
+{
+    return p.group == 1 && p.kernel_h == 1 && p.kernel_w == 1 && p.input_h == 1 && p.input_w == 1 && p.output_h == 1 && p.output_w == 1 &&
+           p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;
+}
+static bool ip_profitable(const fhip_conv_param& p, int batch)
+{
+    return ip_eligible(p) && batch >= 1 && batch <= 32 && p.input_channels >= 1024 && p.output_channels >= 256;
+}
+static int ip_kg(const fhip_conv_param& p) { return ceil_div(p.output_channels, 32); }
+static int ip_kq(const fhip_conv_param& p) { return ceil_div(p.input_channels, 8); }
+static size_t ip_packed_floats(const fhip_conv_param& p) { return (size_t)ip_kg(p) * ip_kq(p) * 256; }
+// pieces of the reduction: about three 4-wave blocks per CU, at least 8 octets (32 MFMAs) per piece
+static int ip_pieces(const fhip_conv_param& p)
+{
+    const int want = device_compute_units() * 3 / std::max(1, ceil_div(ip_kg(p), 4)); // ~3 blocks (of 4 m-groups) per CU: tools/ip_stream_bench.hip
+    return std::max(1, std::min(want, ip_kq(p) / 8));
+}
+static size_t ip_xq_floats(const fhip_conv_param& p) { return round_up_sz((size_t)ip_kq(p) * 256, 64); }
+
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 size_t igemm_packed_floats(const fhip_conv_param& p)
 {
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
-    // [ Wt: the LDS-tiled kernel's panels | wp: the streamed kernel's A-operand image (eligible 1x1 layers only) ]
-    return (size_t)kdp * kp + (stream_eligible(p) ? (size_t)p.output_channels * p.input_channels : 0);
+    // [ Wt: the LDS-tiled kernel's panels | wp: the streamed 1x1 kernel's A-operand image (eligible 1x1 layers only) | the streamed
+    //   InnerProduct kernel's A-operand image (1x1 convolutions over a 1x1 image only) ]
+    return (size_t)kdp * kp + (stream_eligible(p) ? (size_t)p.output_channels * p.input_channels : 0) + (ip_eligible(p) ? ip_packed_floats(p) : 0);
 }
 
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
@@ -70,6 +95,7 @@ void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded)
 static int igemm_split(const fhip_conv_param& p, int batch)
 {
     if (stream_profitable(p, batch)) return 1; // the streamed kernel never splits
+    if (ip_profitable(p, batch)) return 1;     // the streamed InnerProduct has its own pieces (ip_pieces)
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
     const long long ntot = (long long)batch * p.output_h * p.output_w;
@@ -95,6 +121,8 @@ bool igemm_streams(const fhip_conv_param& p, int batch) { return stream_profitab
 
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
 {
+    if (ip_profitable(p, batch)) // [ xq: the re-packed activations | partial sums of the pieces ]
+        return (ip_xq_floats(p) + (size_t)ip_pieces(p) * p.output_channels * batch) * sizeof(float);
     const int s = igemm_split(p, batch);
     if (s <= 1) return 0;
     return (size_t)s * p.output_channels * ((size_t)batch * p.output_h * p.output_w) * sizeof(float);
@@ -145,6 +173,13 @@ int igemm_init(const fhip_conv_param& p, float* packed, const float* kernel, hip
         const size_t kc = (size_t)p.output_channels * p.input_channels;
         hipLaunchKernelGGL(stream_pack_weights_kernel, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, s, packed + (size_t)kdp * kp, kernel,
                            p.output_channels, p.input_channels);
+    }
+    if (ip_eligible(p))
+    {
+        const size_t off = (size_t)kdp * kp + (stream_eligible(p) ? (size_t)p.output_channels * p.input_channels : 0);
+        const long long n4 = (long long)ip_kg(p) * ip_kq(p) * 64;
+        hipLaunchKernelGGL(ip_pack_weights_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, packed + off, kernel, p.output_channels,
+                           p.input_channels, ip_kg(p), ip_kq(p));
     }
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
@@ -511,6 +546,25 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
             default: FHIP_STREAM(8, false, false); break;
         }
 #undef FHIP_STREAM
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
+    }
+    if (!residual && ip_profitable(p, batch))
+    {
+        if (!buffer) return fail(FHIP_E_BADARG, "this geometry streams its weight matrix in pieces and needs the scratch buffer GetBufferSize asked for");
+        IpStreamParams q;
+        q.wp = packed + (size_t)kdp * g.Kp + (stream_eligible(p) ? (size_t)g.K * g.C : 0);
+        q.xq = buffer;
+        q.partial = buffer + ip_xq_floats(p);
+        q.K = g.K;
+        q.Kg = ip_kg(p);
+        q.KQ = ip_kq(p);
+        q.S = ip_pieces(p);
+        q.batch = batch;
+        StageTimer tm(FHIP_STAGE_IGEMM, s);
+        hipLaunchKernelGGL(ip_pack_input_kernel, dim3(ceil_div(q.KQ, kIpPackOctets)), dim3(256), 0, s, buffer, in, batch, g.C, q.KQ);
+        hipLaunchKernelGGL(ip_stream_kernel<4>, dim3((unsigned)q.S * (unsigned)ceil_div(q.Kg, 4)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(ip_reduce_kernel, dim3(ceil_div(g.K * batch, 256)), dim3(256), 0, s, out, q.partial, bias, g.K, batch, q.S, g.has_bias, g.relu);
         FHIP_CHECK_HIP(hipGetLastError());
         return FHIP_OK;
     }

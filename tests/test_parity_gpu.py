@@ -83,6 +83,14 @@ IM2COL = [
     (conv_geom(6, 10, 12, 3, 1, 1), 3),
     (conv_geom(5, 7, 9, 5, 2, 2, w=14), 2),        # 5x5 stride 2 ragged
     (conv_geom(1, 1, 5, 1, 1, 0, group=1), 1),     # degenerate: group == input_channels == 1 -> reference says DEPTHWISE
+    # InnerProduct shapes (a 1x1 convolution over a 1x1 image): the weight-streaming kernel (ip_stream.h) at batch <= 32
+    (conv_geom(4096, 1000, 1, 1, 1, 0), 32),       # VGG-16 fc8: K = 31.25 m-groups, a full column tile of images
+    (conv_geom(4096, 4096, 1, 1, 1, 0), 5),        # fc7 at a ragged batch
+    (conv_geom(1028, 300, 1, 1, 1, 0), 7),         # C % 8 != 0 (zero-padded octet), K % 32 != 0
+    (conv_geom(1024, 256, 1, 1, 1, 0), 1),         # the thresholds of the route, batch 1 (the reference's GEMV case)
+    (conv_geom(25088, 256, 1, 1, 1, 0), 32),       # fc6's reduction length: 3136 octets in pieces of 8 or 9 (loop tails)
+    (conv_geom(1024, 256, 1, 1, 1, 0), 33),        # one image too many: stays on the LDS-tiled kernel
+    (conv_geom(1016, 256, 1, 1, 1, 0), 8),         # below the threshold: LDS-tiled kernel
 ]
 
 

@@ -222,7 +222,7 @@ def roofline_hbm(kernel, nbytes, ms, note):
 # kernels behind each roofline row, as rocprofv3 names them (profiles/<round>_<net>/traffic.json keys)
 TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1>", "ConvGemmPolicy<2>", "stream_gemm_kernel"),
                    "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3>", "ConvGemmPolicy<4>"),
-                   "wino_input_transform_kernel": ("wino_input_transform_kernel",), "wino_chain_kernel": ("wino_chain_kernel",)}
+                   "wino_input_transform_kernel": ("wino_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
 
 
 def attach_traffic(net_name, roofs):
@@ -282,8 +282,8 @@ def attribute(net, reps):
     info = net.layers()
     convs = net.conv_params()
     fused_pw = net.fused_pointwise()
-    chains = net.chains()
-    chain_bytes = 0.0
+    chains = net.chains(raw=True)  # 2 = the pair "first layer computed inside the next layer's input transform"
+    chain_bytes = first_bytes = 0.0
     fz_flops = fz_bytes = fz_ms = 0.0
     by_type, table = {}, []
     gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = pw_bound_ms = direct = 0.0
@@ -299,6 +299,9 @@ def attribute(net, reps):
             row.update({"C": p.input_channels, "K": p.output_channels, "H": p.input_h, "k": p.kernel_h, "s": p.stride_h, "batch": n,
                         "direct_tflops": round(fl / max(ms, 1e-9) / 1e9, 2)})
             a_id = algo_id.get(algo)
+            if chains.get(i, (0, 0))[1] == 2:
+                row["computed_inside_next_input_transform"] = True  # launches nothing (fhip_winograd_f63_input_from_first)
+                first_bytes += 4.0 * p.input_channels * p.input_h * p.input_w * n  # the image, read by the consumer's input transform
             if i in fused_pw and not fused_pw[i][1]:
                 # absorbed pair that runs its two kernels one after the other at this shape: one layer time for both, priced by neither roofline
                 q = fused_pw[i][0]
@@ -319,9 +322,11 @@ def attribute(net, reps):
             elif a_id == WINOGRADF63:
                 tiles = ((p.output_h + 5) // 6) * ((p.output_w + 5) // 6)
                 gemm_flops += 2.0 * 64 * p.output_channels * p.input_channels * tiles * n
-                v_in, v_out = chains.get(i, (False, False))
+                v_in, v_out = chains.get(i, (0, 0))
                 if not v_in:
                     k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
+                elif v_in == 2:
+                    first_bytes += 4.0 * 64 * p.input_channels * tiles * n  # V written by the fused first-layer + input transform
                 else:
                     chain_bytes += 4.0 * 64 * p.input_channels * tiles * n   # V' written by the chained transform of the layer before
                 if v_out:
@@ -368,9 +373,11 @@ def attribute(net, reps):
                                   "of the pointwise layer (the depthwise output never exists) summed over the fused pairs / their HIP-event durations"))
         roofs.append(roofline_mfma("fused depthwise 3x3 + 1x1 (the same launches, matrix side)", fz_flops, fz_ms, "2*K*C*Ho*Wo*N of the pointwise "
                                    "halves / the same durations"))
-    if k2_bytes and stage.get("wino_input"):
-        roofs.append(roofline_hbm("wino_input_transform_kernel", k2_bytes, stage["wino_input"], "4*(C*H*W + 64*C*T)*N summed over the Winograd "
-                                  "layers / sum of the input-transform HIP-event durations"))
+    if (k2_bytes or first_bytes) and stage.get("wino_input"):
+        roofs.append(roofline_hbm("wino_input_transform_kernel / wino_input_from_first_staged_kernel (first layer computed inside it: vector-ALU bound, "
+                                  "1728 FMAs per 64 V values)" if first_bytes else "wino_input_transform_kernel", k2_bytes + first_bytes, stage["wino_input"],
+                                  "4*(C*H*W + 64*C*T)*N summed over the Winograd layers that run an input transform (for the fused first layer: the "
+                                  "image + the consumer's V) / sum of the input-transform HIP-event durations"))
     if chain_bytes and stage.get("wino_chain"):
         roofs.append(roofline_hbm("wino_chain_kernel (output transform [+ max pooling] + next layer's input transform)", chain_bytes,
                                   stage["wino_chain"], "4*64*(K*T + C'*T')*N -- M read, next layer's V written; the activation between the two layers "

@@ -70,6 +70,8 @@ SIGNATURES = {
     "fhip_conv_can_chain_winograd": (_I, [_P, _I, _P, _I, _I]),
     "fhip_conv_forward_chained": (_I, [_P, _I, _V, _V, _V, _V, _V, _V, _P, _V, _I, _V]),
     "fhip_winograd_f63_output_to_next_input": (_I, [_P, _P, _I, _V, _V, _V, _I, _V]),
+    "fhip_conv_can_fuse_first_winograd": (_I, [_P, _P, _I, _I]),
+    "fhip_winograd_f63_input_from_first": (_I, [_P, _P, _I, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_maxpool2": (_I, [_P, _I]),
     "fhip_conv_forward_maxpool2": (_I, [_P, _I, _I, _V, _V, _V, _V, _V, _V]),
     "fhip_pooling_output_dim": (_I, [_Q, _PI, _PI]),

@@ -211,10 +211,18 @@ def can_chain_winograd(a: "ConvLayer", b: "ConvLayer", pool: bool = False) -> bo
     return bool(_lib.load_library().fhip_conv_can_chain_winograd(ctypes.byref(ca), a.booster.algo, ctypes.byref(cb), b.booster.algo, int(pool)))
 
 
-def forward_chained(layers, x, pools=None):
+def can_fuse_first_winograd(first: "ConvParam", nxt: "ConvLayer", batch: int) -> bool:
+    """feather_net.h: can `first` (3x3 / s1 / p1, 2 .. 4 input channels) be computed inside the input transform of the Winograd layer `nxt`?"""
+    cf, cn = first._c(), nxt.param._c()
+    return bool(_lib.load_library().fhip_conv_can_fuse_first_winograd(ctypes.byref(cf), ctypes.byref(cn), nxt.booster.algo, int(batch)))
+
+
+def forward_chained(layers, x, pools=None, first=None):
     """A run of Winograd ConvLayers through fhip_conv_forward_chained: the activations between them never exist (V ping-pongs
     between two scratch buffers).  pools[i] = a 2x2 / stride-2 max pooling follows layer i.  Every adjacent pair must satisfy
-    can_chain_winograd.  -> output of the last layer (pooled if pools[-1])."""
+    can_chain_winograd.  first = (ConvParam, filters [K][C][3][3], bias or None) of a convolution in FRONT of layers[0] that is computed
+    inside layers[0]'s input transform (fhip_winograd_f63_input_from_first; `x` is then that convolution's input).
+    -> output of the last layer (pooled if pools[-1])."""
     import torch
     lib = _lib.load_library()
     pools = list(pools) if pools is not None else [False] * len(layers)
@@ -229,10 +237,16 @@ def forward_chained(layers, x, pools=None):
     last = layers[-1].param
     oh, ow = (last.output_h // 2, last.output_w // 2) if pools[-1] else (last.output_h, last.output_w)
     out = torch.empty((batch, last.output_channels, oh, ow), dtype=torch.float32, device=dev)
+    if first is not None:
+        fprm, fw, fb = first
+        fprm.batch = batch
+        cf, c0 = fprm._c(), layers[0].param._c()
+        _check(lib.fhip_winograd_f63_input_from_first(ctypes.byref(cf), ctypes.byref(c0), batch, _ptr(vbuf[0]), _ptr(x), _ptr(fw),
+                                                      _ptr(fb) if fb is not None else None, _stream()), "fhip_winograd_f63_input_from_first")
     for i, l in enumerate(layers):
         c = l.param._c()
         nxt = layers[i + 1].param._c() if i + 1 < len(layers) else None
-        _check(lib.fhip_conv_forward_chained(ctypes.byref(c), batch, _ptr(out) if nxt is None else None, _ptr(x) if i == 0 else None,
+        _check(lib.fhip_conv_forward_chained(ctypes.byref(c), batch, _ptr(out) if nxt is None else None, _ptr(x) if i == 0 and first is None else None,
                                              _ptr(l.packed), _ptr(vbuf[i & 1]), _ptr(m), _ptr(l.bias) if l.bias is not None else None,
                                              ctypes.byref(nxt) if nxt is not None else None, _ptr(vbuf[(i + 1) & 1]) if nxt is not None else None,
                                              int(pools[i]), _stream()), "fhip_conv_forward_chained")

@@ -22,6 +22,9 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
                               hipStream_t s, int pool = 0);
 bool winograd_can_pool(const fhip_conv_param& p);
 bool winograd_can_chain(const fhip_conv_param& p, const fhip_conv_param& next, int pool);
+bool winograd_can_fuse_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch);
+int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch, float* v, const float* input,
+                              const float* first_kernel, const float* first_bias, hipStream_t s);
 int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_param& next, int batch, float* vn, const float* m, const float* bias,
                                   hipStream_t s, int pool);
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
@@ -311,6 +314,18 @@ int fhip_winograd_f63_output_to_next_input(const fhip_conv_param* p, const fhip_
 {
     if (!valid_param(p) || !valid_param(next) || !v_next || !m || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
     return winograd_output_to_next_input(*p, *next, batch, v_next, m, bias, (hipStream_t)stream, pool);
+}
+
+int fhip_conv_can_fuse_first_winograd(const fhip_conv_param* first, const fhip_conv_param* next, int next_algo, int batch)
+{
+    return valid_param(first) && valid_param(next) && next_algo == FHIP_WINOGRADF63 && winograd_can_fuse_first(*first, *next, batch) ? 1 : 0;
+}
+
+int fhip_winograd_f63_input_from_first(const fhip_conv_param* first, const fhip_conv_param* next, int batch, float* v_next, const float* input,
+                                       const float* first_kernel, const float* first_bias, void* stream)
+{
+    if (!valid_param(first) || !valid_param(next) || !v_next || !input || !first_kernel || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
+    return winograd_input_from_first(*first, *next, batch, v_next, input, first_kernel, first_bias, (hipStream_t)stream);
 }
 
 int fhip_winograd_f63_transform_kernel(const fhip_conv_param* p, float* u, const float* kernel, void* stream)

@@ -436,6 +436,17 @@ struct ConvLayer : Layer
     bool chain_in = false;
     int chain_pos = 0;
     size_t chain_bytes = 0; // arena the run needs (reported instead of buffer_bytes)
+    // fusion level 3 (plan_chains): a first layer (3x3 / s1 / p1, 2 .. 4 input channels) whose only consumer is a Winograd layer is computed
+    // inside that layer's input transform (fhip_winograd_f63_input_from_first): `head_of` = the consumer (this layer then launches nothing,
+    // its top has no storage), `head` = the absorbed first layer (on the consumer); first_raw = this layer's filters as loaded
+    ConvLayer* head_of = nullptr;
+    ConvLayer* head = nullptr;
+    DeviceVec first_raw;
+    bool first_candidate() const
+    {
+        return p.kernel_h == 3 && p.kernel_w == 3 && p.stride_h == 1 && p.stride_w == 1 && p.group == 1 && p.input_channels >= 2 && p.input_channels <= 4 && p.pad_left == 1 &&
+               p.pad_right == 1 && p.pad_top == 1 && p.pad_bottom == 1;
+    }
 
     ConvLayer()
     {
@@ -555,6 +566,7 @@ struct ConvLayer : Layer
         DeviceVec raw;
         int rc = raw.upload(w.data(), w.size(), s);
         if (rc) return rc;
+        if (first_candidate() && (rc = first_raw.upload(w.data(), w.size(), s))) return rc; // 27 floats per output channel
         rc = packed.resize(packed_bytes);
         if (rc) return rc;
         rc = fhip_conv_init(&p, algo_, packed.d, raw.d, s);
@@ -571,6 +583,7 @@ struct ConvLayer : Layer
     int Forward(hipStream_t s) override
     {
         const float* b = p.bias_term ? bias.d : nullptr;
+        if (head_of) return 0; // computed inside head_of's input transform
         if (pw)
         {
             const float* pb = pw->p.bias_term ? pw->bias.d : nullptr;
@@ -591,14 +604,20 @@ struct ConvLayer : Layer
             dwout.data = nullptr;
             return rc;
         }
-        if (chain_in || chain_next)
+        if (chain_in || chain_next || head)
         {
             char* base = reinterpret_cast<char*>(net->arena.d);
             float* v = reinterpret_cast<float*>(base + net->chain_slot[chain_pos & 1]);
             float* vn = reinterpret_cast<float*>(base + net->chain_slot[(chain_pos + 1) & 1]);
             float* m = reinterpret_cast<float*>(base + net->chain_m);
-            const float* in = chain_in ? nullptr : bottoms[0]->data;
+            const float* in = chain_in || head ? nullptr : bottoms[0]->data;
             const int n = bottoms[0]->n;
+            if (head)
+            {
+                const int rc = fhip_winograd_f63_input_from_first(&head->p, &p, n, v, head->bottoms[0]->data, head->first_raw.d,
+                                                                  head->p.bias_term ? head->bias.d : nullptr, s);
+                if (rc) return rc;
+            }
             if (chain_next) return fhip_conv_forward_chained(&p, n, nullptr, in, packed.d, v, m, b, &chain_next->p, vn, fuse_pool ? 1 : 0, s);
             if (!fuse_pool || pool_fast) return fhip_conv_forward_chained(&p, n, tops[0]->data, in, packed.d, v, m, b, nullptr, nullptr, fuse_pool ? 1 : 0, s);
             const int rc = fhip_conv_forward_chained(&p, n, pre_pool.d, in, packed.d, v, m, b, nullptr, nullptr, 0, s);
@@ -642,7 +661,10 @@ struct ConvLayer : Layer
         bottoms.push_back(other); // so that dependency scans (fusion, branch concurrency) see the second input
         return true;
     }
-    size_t weight_bytes() const override { return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + (pw ? pw->weight_bytes() : 0); }
+    size_t weight_bytes() const override
+    {
+        return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + first_raw.bytes + (pw ? pw->weight_bytes() : 0);
+    }
     const fhip_conv_param* fused_pointwise(int* one_kernel) const override
     {
         if (one_kernel) *one_kernel = pair_fast ? 1 : 0;
@@ -653,8 +675,8 @@ struct ConvLayer : Layer
     int algo() const override { return algo_; }
     void chain_state(int* v_from_previous, int* writes_next_v) const override
     {
-        *v_from_previous = chain_in ? 1 : 0;
-        *writes_next_v = chain_next ? 1 : 0;
+        *v_from_previous = head ? 2 : chain_in ? 1 : 0;
+        *writes_next_v = head_of ? 2 : chain_next ? 1 : 0;
     }
 };
 
@@ -1297,6 +1319,7 @@ static int plan_chains(Net& net)
             conv[i]->chain_in = false;
             conv[i]->chain_pos = 0;
             conv[i]->chain_bytes = 0;
+            conv[i]->head = conv[i]->head_of = nullptr;
         }
     for (auto& kv : net.blobs) kv.second->chained = false;
     for (auto& b : net.shadowed) b->chained = false; // blobs whose name a later top re-used (in-place style .param files) re-plan too
@@ -1319,6 +1342,22 @@ static int plan_chains(Net& net)
         a->tops[0]->chained = true;
         a->tops[0]->drop_storage();
     }
+    // a first layer in front of a Winograd layer (VGG-16: conv1_1 -> conv1_2) is computed inside that layer's input transform
+    for (size_t i = 0; i + 1 < L; ++i)
+    {
+        ConvLayer *a = conv[i], *b = conv[i + 1];
+        if (!a || a->pw || a->residual || a->fuse_pool || a->chain_in || a->chain_next || a->tops.size() != 1 || a->bottoms.size() != 1) continue;
+        if (!a->first_candidate() || !plain(b) || b->chain_in || b->bottoms[0] != a->tops[0]) continue;
+        int uses = 0;
+        for (size_t j = 0; j < L; ++j)
+            for (Blob* x : net.layers[j]->bottoms) uses += (x == a->tops[0] || x->alias == a->tops[0]) ? 1 : 0;
+        if (uses != 1) continue;
+        if (!fhip_conv_can_fuse_first_winograd(&a->p, &b->p, b->algo_, a->bottoms[0]->n)) continue;
+        a->head_of = b;
+        b->head = a;
+        a->tops[0]->chained = true;
+        a->tops[0]->drop_storage();
+    }
     // blobs the previous plan had chained and this one did not: Reshape left them without storage
     auto restore = [](Blob* b) -> int {
         if (b->chained || b->data || b->alias || b->fused_away || b->count() == 0) return 0;
@@ -1335,7 +1374,7 @@ static int plan_chains(Net& net)
     for (size_t i = 0; i < L; ++i)
     {
         ConvLayer* c = conv[i];
-        if (!c || (!c->chain_in && !c->chain_next)) continue;
+        if (!c || (!c->chain_in && !c->chain_next && !c->head)) continue;
         fhip_winograd_plan pl;
         const int rc = fhip_winograd_f63_plan(&c->p, c->bottoms[0]->n, &pl);
         if (rc) return rc;
@@ -1346,7 +1385,7 @@ static int plan_chains(Net& net)
     net.chain_slot[1] = slot[0];
     net.chain_m = slot[0] + slot[1];
     for (size_t i = 0; i < L; ++i)
-        if (conv[i] && (conv[i]->chain_in || conv[i]->chain_next)) conv[i]->chain_bytes = slot[0] + slot[1] + msz;
+        if (conv[i] && (conv[i]->chain_in || conv[i]->chain_next || conv[i]->head)) conv[i]->chain_bytes = slot[0] + slot[1] + msz;
     return 0;
 }
 

@@ -161,6 +161,11 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __rest
         for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * xi_stride] = d[i][j];
 }
 
+} // namespace fhip
+#include "wino_first.h" // K2 with the net's first (<= 4-channel) convolution computed in place of the loads
+namespace fhip
+{
+
 // (An LDS-staged form of K2 -- coalesced 16-byte row loads into LDS, patches read from LDS -- was built and measured
 // SLOWER than this direct form on every VGG layer (1.37 ms vs 0.87 ms per step): the staging pass, its index
 // arithmetic and the extra barrier cost more than the uncoalesced 8-float patch loads, which the L1/L2 absorb.)
@@ -577,6 +582,76 @@ int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, cons
     if ((work + 255) / 256 > 0x7fffffffLL) return fail(FHIP_E_BADARG, "input transform grid too large");
     dim3 grid((unsigned)((work + 255) / 256));
     hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
+// The first layer (3x3 / stride 1 / pad 1, 2 .. 4 input channels -- with 1 channel and group 1 ConvParam makes it a depthwise layer,
+// booster.h:113-125 --, any number of output channels) inside the input transform of `next`,
+// the 3x3 / stride-1 / pad-1 Winograd layer that is its only consumer (wino_first.h).
+bool winograd_can_fuse_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch)
+{
+    auto k3p1 = [](const fhip_conv_param& c) {
+        return c.kernel_h == 3 && c.kernel_w == 3 && c.stride_h == 1 && c.stride_w == 1 && c.group == 1 && c.pad_left == 1 && c.pad_right == 1 &&
+               c.pad_top == 1 && c.pad_bottom == 1;
+    };
+    if (!k3p1(first) || !k3p1(next) || batch < 1) return false;
+    if (first.input_channels < 2 || first.input_channels > 4 || next.input_channels != first.output_channels) return false;
+    if (first.activation != FHIP_ACT_NONE && first.activation != FHIP_ACT_RELU) return false;
+    if (next.input_h != first.input_h || next.input_w != first.input_w || (first.input_w & 1)) return false; // float2 image reads: even rows
+    const unsigned long long in_bytes = 4ull * batch * first.input_channels * first.input_h * first.input_w;
+    return in_bytes < kWinoFirstOob && first.output_channels <= 65535;
+}
+
+int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch, float* v, const float* input,
+                              const float* first_kernel, const float* first_bias, hipStream_t s)
+{
+    if (!winograd_can_fuse_first(first, next, batch))
+        return fail(FHIP_E_UNSUPPORTED, "this first layer cannot be computed inside the next layer's input transform (fhip_conv_can_fuse_first_winograd)");
+    if (first.bias_term && !first_bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
+    fhip_winograd_plan pl;
+    const int rc = winograd_plan(next, batch, &pl);
+    if (rc) return rc;
+    WinoFirstParams q;
+    q.in = input;
+    q.w = first_kernel;
+    q.bias = first.bias_term ? first_bias : nullptr;
+    q.V = v;
+    q.K = first.output_channels;
+    q.H = first.input_h;
+    q.W = first.input_w;
+    q.TX = pl.tiles_x;
+    q.T = pl.tiles_per_image;
+    q.P = pl.columns;
+    q.Pp = pl.columns_padded;
+    q.in_bytes = (unsigned)(4ull * batch * first.input_channels * first.input_h * first.input_w);
+    q.relu = first.activation == FHIP_ACT_RELU;
+    StageTimer tm(FHIP_STAGE_WINO_INPUT, s);
+    // staged form: 64 consecutive tiles of an image span at most floor((TX + 62) / TX) + 1 tile rows
+    q.N = batch;
+    q.bpi = ceil_div(q.T, kFirstTiles);
+    q.LDW = 6 * q.TX + 4;
+    q.rows = 6 * std::min(pl.tiles_y, (q.TX + kFirstTiles - 2) / q.TX + 1) + 4;
+    const size_t lds = (size_t)first.input_channels * q.rows * q.LDW * sizeof(float);
+    if (lds <= 64 * 1024 && q.LDW <= 256 && (long long)q.bpi * batch <= 0x7fffffffLL) // 128 float2 columns: one per thread pair
+    {
+        const dim3 grid((unsigned)(q.bpi * batch), (unsigned)ceil_div(q.K, kFirstCpb));
+        switch (first.input_channels)
+        {
+            case 2: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<2>, grid, dim3(256), lds, s, q); break;
+            case 3: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<3>, grid, dim3(256), lds, s, q); break;
+            default: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<4>, grid, dim3(256), lds, s, q); break;
+        }
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
+    }
+    const dim3 grid((unsigned)ceil_div(q.P, 256), (unsigned)q.K); // image rows too wide for the LDS: read them through the L1
+    switch (first.input_channels)
+    {
+        case 2: hipLaunchKernelGGL(wino_input_from_first_kernel<2>, grid, dim3(256), 0, s, q); break;
+        case 3: hipLaunchKernelGGL(wino_input_from_first_kernel<3>, grid, dim3(256), 0, s, q); break;
+        default: hipLaunchKernelGGL(wino_input_from_first_kernel<4>, grid, dim3(256), 0, s, q); break;
+    }
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }

@@ -134,13 +134,14 @@ class Net:
                 out[i] = (p, bool(one.value))
         return out
 
-    def chains(self):
-        """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3)."""
+    def chains(self, raw=False):
+        """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3).
+        raw=True keeps the library's values: 2 marks the pair "first layer computed inside the next layer's input transform"."""
         out = {}
         for i in range(self._lib.fhip_net_layer_count(self._h)):
             a, b = ctypes.c_int(), ctypes.c_int()
             if self._lib.fhip_net_layer_chain(self._h, i, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value or b.value):
-                out[i] = (bool(a.value), bool(b.value))
+                out[i] = (a.value, b.value) if raw else (bool(a.value), bool(b.value))
         return out
 
     def forward_timed(self):

@@ -105,6 +105,20 @@ FHIP_API int fhip_conv_forward_chained(const fhip_conv_param* param, int batch, 
 FHIP_API int fhip_winograd_f63_output_to_next_input(const fhip_conv_param* param, const fhip_conv_param* next, int batch, float* v_next,
                                                     const float* m, const float* bias, int pool, void* stream);
 
+/* A net's first convolution inside the Winograd layer behind it.  `first` is a 3x3 / stride-1 / pad-1 convolution with 2 .. 4 input
+ * channels (VGG-16's conv1_1: ConvLayer::Forward through the im2col + SGEMM route, conv_layer.h:141-150, avx/booster.cpp:108-160) whose
+ * only consumer `next` is a 3x3 / stride-1 / pad-1 WINOGRADF63 layer.  Its output is as large as the largest tensor of the net and holds
+ * 27 multiply-adds per value, so next's input transform can compute every activation value of its 8x8 windows from the image instead
+ * of loading it: V(next) = B^T act(first(image)) B with the consumer's zero padding outside the image; the first layer's output never
+ * exists in memory.  `first_kernel` are first's filters as loaded ([K][C][3][3], device), `first_bias` its bias or NULL; the image
+ * must be under 1 GiB and its width even.
+ *   fhip_conv_can_fuse_first_winograd: 1 when the pair qualifies at this batch.
+ *   fhip_winograd_f63_input_from_first writes next's V (fhip_winograd_plan(next).v_bytes); run the rest of `next` with
+ *     fhip_conv_forward_chained(next, ..., input = NULL, v = that buffer, ...). */
+FHIP_API int fhip_conv_can_fuse_first_winograd(const fhip_conv_param* first, const fhip_conv_param* next, int next_algo, int batch);
+FHIP_API int fhip_winograd_f63_input_from_first(const fhip_conv_param* first, const fhip_conv_param* next, int batch, float* v_next,
+                                                const float* input, const float* first_kernel, const float* first_bias, void* stream);
+
 /* ---- feather::Net on device blobs --------------------------------------------------------------------- */
 
 /* Opaque handle to a feather::Net (include/feather/net.h; reference net.h:30-70). */
@@ -120,7 +134,9 @@ FHIP_API int fhip_net_set_stream(fhip_net* net, void* stream);
  *      BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.
  *   2: + BatchNorm / Scale folded into the convolution before them, Conv + 2x2 max pooling, Conv + Eltwise SUM (+ReLU), and a 3x3
  *      depthwise layer + the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw where the pair qualifies).
- *   3: + runs of Winograd layers chained (fhip_conv_forward_chained): the blob between two chained layers has a shape but no storage.
+ *   3: + runs of Winograd layers chained (fhip_conv_forward_chained): the blob between two chained layers has a shape but no storage;
+ *      a first layer (3x3 / stride 1 / pad 1, 2 .. 4 input channels) in front of a Winograd layer is computed inside that layer's input
+ *      transform (fhip_winograd_f63_input_from_first): its top has no storage either.
  * A blob that a fusion removed cannot be extracted (fhip_net_extract fails and says which level to use). */
 FHIP_API int fhip_net_set_fusion(fhip_net* net, int on);
 /* 1: convolutions choose their route with fhip_conv_select_algo_tuned (MI355X cost model) instead of the reference's
@@ -187,7 +203,9 @@ FHIP_API int fhip_net_layer_conv_param(fhip_net* net, int index, fhip_conv_param
  * FHIP_E_BADARG for every other layer. */
 FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_param* param, int* one_kernel);
 /* Fusion level 3: *v_from_previous = 1 when this convolution's transformed input is written by the layer before it (it runs no input
- * transform), *writes_next_v = 1 when its output leaves as the next layer's transformed input (fhip_conv_forward_chained). */
+ * transform), *writes_next_v = 1 when its output leaves as the next layer's transformed input (fhip_conv_forward_chained).  The value
+ * is 2 for the pair "first layer computed inside the next layer's input transform" (fhip_winograd_f63_input_from_first): writes_next_v =
+ * 2 on the first layer (it launches nothing), v_from_previous = 2 on the Winograd layer behind it. */
 FHIP_API int fhip_net_layer_chain(fhip_net* net, int index, int* v_from_previous, int* writes_next_v);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);

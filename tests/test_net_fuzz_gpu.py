@@ -164,8 +164,14 @@ def test_random_topology_with_winograd_runs_at_fusion_level_3(seed, cuda):
             outs[fusion] = net.Extract(out)
             if fusion == 3:
                 chained += len(net.chains())
+                first_fused = any(2 in v for v in net.chains(raw=True).values())
             net.close()
-        assert np.array_equal(outs[2], outs[3], equal_nan=True), (seed, tuned)
+        if first_fused:  # the first layer's 27-term sums are added in another order inside the next layer's input transform
+            assert np.array_equal(np.isnan(outs[2]), np.isnan(outs[3])), (seed, tuned)
+            m = ~np.isnan(outs[2])
+            assert not m.any() or float(np.abs(outs[2][m] - outs[3][m]).max()) <= 1e-5 * max(float(np.abs(outs[2][m]).max()), 1e-30), (seed, tuned)
+        else:
+            assert np.array_equal(outs[2], outs[3], equal_nan=True), (seed, tuned)
         assert np.array_equal(np.isnan(outs[3]), ~ok), (seed, tuned)
         if ok.any() and float(np.abs(want[ok]).max()) > 0:
             assert float(np.abs(outs[3][ok] - want[ok]).max()) <= TOL * float(np.abs(want[ok]).max()), (seed, tuned, p.decode())

@@ -117,21 +117,25 @@ def _net_outputs(p, b, img, level, blob, graph=False):
 
 
 def test_net_fusion_level_3_chains_vgg_and_equals_level_2(cuda):
-    """VGG-16 at 64 x 64 (same layer structure as the benchmark net): level 3 chains conv1_2 ... conv5_3 -- bit-identical logits to
-    level 2, the blobs in between are gone, the arena holds two V slots + M."""
+    """VGG-16 at 64 x 64 (same layer structure as the benchmark net): level 3 chains conv1_2 ... conv5_3 and computes conv1_1 inside
+    conv1_2's input transform -- the same logits as level 2 to rounding (bit-identical but for conv1_1's summation order), the blobs in
+    between are gone, the arena holds two V slots + M."""
     from feathercnn_amd import model_zoo
     p, b, i, o = model_zoo.vgg16(size=64, classes=10)
     img = np.random.default_rng(3).uniform(-1, 1, (3, 3, 64, 64)).astype(np.float32)
     net2, out2 = _net_outputs(p, b, img, 2, "fc8")
     net3, out3 = _net_outputs(p, b, img, 3, "fc8", graph=True)
-    assert np.array_equal(out2, out3)
-    ch = net3.chains()
+    assert nerr(out3, out2) <= 1e-5
+    ch = net3.chains(raw=True)
     names = {net3.layers()[k][1]: v for k, v in ch.items()}
     convs = [n for t, n, _ in net3.layers() if t == "Convolution"]
     wino = [n for t, n, a in net3.layers() if t == "Convolution" and a == "WINOGRADF63"]
-    assert len(wino) >= 10 and set(names) == set(wino), (convs, names)
-    assert names[wino[0]] == (False, True) and names[wino[-1]] == (True, False)
-    assert all(names[n] == (True, True) for n in wino[1:-1])
+    assert len(wino) >= 10 and set(names) == set(wino) | {convs[0]}, (convs, names)
+    assert convs[0] not in wino and names[convs[0]] == (0, 2)       # conv1_1: launches nothing
+    assert names[wino[0]] == (2, 1) and names[wino[-1]] == (1, 0)   # conv1_2: V from the fused transform
+    assert all(names[n] == (1, 1) for n in wino[1:-1])
+    with pytest.raises(Exception):
+        net3.Extract(convs[0])  # conv1_1's output does not exist
     assert not net2.chains()
     with pytest.raises(Exception, match="fusion level 3"):
         net3.Extract("pool2")  # between conv2_2 (+pool) and conv3_1: no storage at level 3

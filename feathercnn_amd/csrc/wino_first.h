@@ -162,14 +162,19 @@ constexpr int kFirstCpb = 16;   // output channels per block, 4 per wave (tools/
 constexpr int kFirstStage = 12; // image loads a thread keeps in flight while staging
 constexpr int kFirstWaves = 4;  // waves per block (8 waves at 128 registers spill: 392 us)
 constexpr bool kFirstHoist = true;
+constexpr bool kFirstXcd = true;
 constexpr int kFirstTiles = 64; // tiles per block
 
-template <int CIN, int CPB = kFirstCpb, bool HOIST = kFirstHoist, int WAVES = kFirstWaves>
+template <int CIN, int CPB = kFirstCpb, bool HOIST = kFirstHoist, int WAVES = kFirstWaves, bool XCD = kFirstXcd>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_staged_kernel(const WinoFirstParams q)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[]; // [CIN][rows][LDW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x / q.bpi, b = blockIdx.x - n * q.bpi;
+    // consecutive tile blocks on the same XCD: their 256-byte V runs share cache lines at both ends (p = n T + t is 16-byte aligned at
+    // best), which only merge into whole-line writes inside one L2
+    const int lin = XCD ? xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+    const int bx = lin % gridDim.x, by = lin / gridDim.x;
+    const int n = bx / q.bpi, b = bx - n * q.bpi;
     const int t0 = b * kFirstTiles, nt = min(kFirstTiles, q.T - t0);
     const int ty0 = t0 / q.TX, ty1 = (t0 + nt - 1) / q.TX;
     const int rows = 6 * (ty1 - ty0 + 1) + 4; // image rows 6 ty0 - 2 ... 6 ty1 + 7
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
         row_lo[j] = rowok ? lo : 0.f;
         row_hi[j] = rowok ? __builtin_huge_valf() : 0.f;
     }
-    const int kbase = blockIdx.y * CPB;
+    const int kbase = by * CPB;
     for (int kk = wave; kk < CPB; kk += WAVES)
     {
         const int k = __builtin_amdgcn_readfirstlane(kbase + kk);

@@ -384,7 +384,9 @@ __global__ __launch_bounds__(512) void wino_chain_kernel(float* __restrict__ Vn,
 {
     extern __shared__ __attribute__((aligned(16))) float smem[]; // [ppb][LDH][LDW]
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int plane0 = blockIdx.x * g.ppb;
+    // consecutive blocks on the same XCD: the planes of neighbouring blocks are neighbouring column runs of M and V', which share cache lines
+    // at both ends -- they merge into whole-line traffic only inside one L2 (tools/chain_bench.py: -2 ... -9 % per boundary on VGG-16)
+    const int plane0 = xcd_remap(blockIdx.x, gridDim.x) * g.ppb;
     const int np = min(g.ppb, g.planes - plane0);
     const int plane_floats = g.LDH * g.LDW;
     // Phase 1 writes rows 1 .. AH x columns 2 .. 2 + CW - 1 of every plane (CW = the columns layer L's tiles cover; cells beyond the image are

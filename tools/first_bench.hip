@@ -26,6 +26,16 @@ __device__ __forceinline__ void bt8(float& r0, float& r1, float& r2, float& r3, 
 using namespace fhip;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+__global__ __launch_bounds__(256) void copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void spin_kernel(long long ticks) // one wave waiting on the 100 MHz clock
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
 static hipEvent_t g_a, g_b;
 template <class F>
 static double time_us(F&& f)
@@ -81,6 +91,52 @@ int main(int argc, char** argv)
     {
         std::sort(v.t.begin(), v.t.end());
         printf("%-14s median %7.1f us  min %7.1f\n", v.name, v.t[v.t.size() / 2], v.t[0]);
+    }
+    // the kernel AFTER it: a 757 MB -> 757 MB copy (what conv1_2's tile GEMM is to the memory system) launched back to back behind (a) another
+    // copy, (b) the staged kernel, (c) the staged kernel + an idle gap, (d) the direct (L1-bound) form; events around the copy only
+    float4* dst;
+    const size_t vbytes = (size_t)64 * K * Pp * 4;
+    CK(hipMalloc(&dst, vbytes));
+    auto copy = [&] { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, dst, (const float4*)V, vbytes / 16); };
+    auto staged = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, false>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
+    auto staged_xcd = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
+    float* V2;
+    CK(hipMalloc(&V2, vbytes));
+    WinoFirstParams q2 = q;
+    q2.V = V2;
+    auto staged_other = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q2); };
+    auto copy_back = [&] { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, (float4*)V, (const float4*)dst, vbytes / 16); };
+    auto direct = [&] { hipLaunchKernelGGL(wino_input_from_first_kernel<3>, dim3((unsigned)((P + 255) / 256), K), dim3(256), 0, 0, q); };
+    struct Seq { const char* name; std::vector<double> t; } seqs[] = {{"copy after copy", {}}, {"copy after staged", {}}, {"copy after staged + 100 us idle", {}},
+                                                                       {"copy after staged, XCD-contiguous", {}}, {"copy after direct", {}}, {"staged", {}}, {"staged, XCD-contiguous", {}}, {"copy V->dst after copy dst->V (source freshly written by a streaming kernel)", {}},
+                                                                       {"copy V->dst after staged wrote ANOTHER buffer", {}}};
+    for (int r = 0; r < reps + 1; ++r)
+    {
+        double t[9];
+        copy();
+        t[0] = time_us(copy);
+        staged();
+        t[1] = time_us(copy);
+        staged();
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, 0, 10000LL);
+        t[2] = time_us(copy);
+        staged_xcd();
+        t[3] = time_us(copy);
+        direct();
+        t[4] = time_us(copy);
+        t[5] = time_us(staged);
+        t[6] = time_us(staged_xcd);
+        copy_back();
+        t[7] = time_us(copy);
+        staged_other();
+        t[8] = time_us(copy);
+        if (r)
+            for (int i = 0; i < 9; ++i) seqs[i].t.push_back(t[i]);
+    }
+    for (auto& v : seqs)
+    {
+        std::sort(v.t.begin(), v.t.end());
+        printf("%-40s median %7.1f us  min %7.1f\n", v.name, v.t[v.t.size() / 2], v.t[0]);
     }
     return 0;
 }

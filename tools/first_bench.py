@@ -51,16 +51,27 @@ def main():
         b.record()
         b.synchronize()
         return a.elapsed_time(b) * 1e3
-    res = {"conv1_1": [], "input transform": [], "fused": []}
+    m = torch.empty(pl.m_bytes // 4, dtype=torch.float32, device=dev)
+
+    def gemm():
+        assert lib.fhip_winograd_f63_tile_gemm(ctypes.byref(cn), batch, _ptr(m), _ptr(nxt.packed), _ptr(v), _stream()) == 0
+    res = {"conv1_1": [], "input transform": [], "fused": [], "gemm after input transform": [], "gemm after fused": [], "gemm after gemm": []}
     for f in (conv1, k2, fused):
         f()
     for _ in range(reps):
         res["conv1_1"].append(timed(conv1))
         res["input transform"].append(timed(k2))
         res["fused"].append(timed(fused))
+        k2()
+        res["gemm after input transform"].append(timed(gemm))
+        fused()
+        res["gemm after fused"].append(timed(gemm))
+        res["gemm after gemm"].append(timed(gemm))
     med = {k: float(np.median(t)) for k, t in res.items()}
     print(f"batch {batch}: conv1_1 {med['conv1_1']:.1f} us + input transform {med['input transform']:.1f} us = "
           f"{med['conv1_1'] + med['input transform']:.1f} us;  fused {med['fused']:.1f} us  (min {min(res['fused']):.1f})")
+    print("tile GEMM of conv1_2 right after the input transform %.1f us, after the fused kernel %.1f us, after itself %.1f us" %
+          (med["gemm after input transform"], med["gemm after fused"], med["gemm after gemm"]))
 
 
 if __name__ == "__main__":

@@ -220,8 +220,8 @@ def roofline_hbm(kernel, nbytes, ms, note):
 
 
 # kernels behind each roofline row, as rocprofv3 names them (profiles/<round>_<net>/traffic.json keys)
-TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1>", "ConvGemmPolicy<2>", "stream_gemm_kernel"),
-                   "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3>", "ConvGemmPolicy<4>"),
+TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1", "ConvGemmPolicy<2", "stream_gemm_kernel"),
+                   "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3", "ConvGemmPolicy<4"),
                    "wino_input_transform_kernel": ("wino_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
 
 
@@ -282,6 +282,7 @@ def attribute(net, reps):
     info = net.layers()
     convs = net.conv_params()
     fused_pw = net.fused_pointwise()
+    siblings = net.siblings()      # 1: this 1x1 layer's launch also computes the next layer, 2: that next layer (launches nothing)
     chains = net.chains(raw=True)  # 2 = the pair "first layer computed inside the next layer's input transform"
     chain_bytes = first_bytes = 0.0
     fz_flops = fz_bytes = fz_ms = 0.0
@@ -338,15 +339,29 @@ def attribute(net, reps):
             elif a_id == IM2COL and p.kernel_h == 1 and p.kernel_w == 1:
                 pw_flops += fl
                 pw_ms += ms
-                row["mfma_frac"] = round(fl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)
-                pw_rows.append(row["mfma_frac"])
+                by = 4.0 * ((p.input_channels + p.output_channels) * p.output_h * p.output_w * n + p.input_channels * p.output_channels)
+                if siblings.get(i) == 2:
+                    # computed by the launch of the layer before (fhip_conv_forward_siblings): its work joins that row, it has no time of its own
+                    row["computed_with_previous_layer"] = True
+                    prev = table[-1]
+                    prev["sibling_K"] = p.output_channels
+                    fl += prev.pop("_fl")
+                    by += prev.pop("_by") - 4.0 * p.input_channels * p.output_h * p.output_w * n  # the shared input is read once
+                    ms, row_ = prev["ms"], prev
+                    pw_rows.pop()
+                    pw_bound_ms -= prev.pop("_bound_ms")
+                else:
+                    row_ = row
+                row_["mfma_frac"] = round(fl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)
+                pw_rows.append(row_["mfma_frac"])
                 # the layer's own lower bound: its matrix work at the MFMA peak or its compulsory bytes (the pixels the stride keeps, the
                 # output, the weights; a fused residual operand is NOT counted) at the HBM peak, whichever is longer
-                by = 4.0 * ((p.input_channels + p.output_channels) * p.output_h * p.output_w * n + p.input_channels * p.output_channels)
                 t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e9), by / (PEAK_HBM_GBS * 1e6)
                 pw_bound_ms += max(t_mfma, t_hbm)
-                row["bound"] = "hbm" if t_hbm > t_mfma else "mfma"
-                row["bound_frac"] = round(max(t_mfma, t_hbm) / max(ms, 1e-9), 4)
+                row_["bound"] = "hbm" if t_hbm > t_mfma else "mfma"
+                row_["bound_frac"] = round(max(t_mfma, t_hbm) / max(ms, 1e-9), 4)
+                if siblings.get(i) == 1:
+                    row["_fl"], row["_by"], row["_bound_ms"] = fl, by, max(t_mfma, t_hbm)
         table.append(row)
     roofs = []
     if gemm_flops and stage.get("wino_gemm"):

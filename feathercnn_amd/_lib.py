@@ -70,6 +70,9 @@ SIGNATURES = {
     "fhip_conv_can_chain_winograd": (_I, [_P, _I, _P, _I, _I]),
     "fhip_conv_forward_chained": (_I, [_P, _I, _V, _V, _V, _V, _V, _V, _P, _V, _I, _V]),
     "fhip_winograd_f63_output_to_next_input": (_I, [_P, _P, _I, _V, _V, _V, _I, _V]),
+    "fhip_conv_can_fuse_siblings": (_I, [_P, _I, _P, _I, _I]),
+    "fhip_conv_siblings_geometry": (_I, [_P, _P, _P]),
+    "fhip_conv_forward_siblings": (_I, [_P, _P, _I, _V, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_first_winograd": (_I, [_P, _P, _I, _I]),
     "fhip_winograd_f63_input_from_first": (_I, [_P, _P, _I, _V, _V, _V, _V, _V]),
     "fhip_conv_can_fuse_maxpool2": (_I, [_P, _I]),
@@ -100,6 +103,7 @@ SIGNATURES = {
     "fhip_net_layer_conv_param": (_I, [_V, _I, _P, _PI]),
     "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P, _PI]),
     "fhip_net_layer_chain": (_I, [_V, _I, _PI, _PI]),
+    "fhip_net_layer_sibling": (_I, [_V, _I, _PI]),
     "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
     "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }

@@ -185,6 +185,43 @@ class ConvLayer:
         return out
 
 
+class SiblingConvs:
+    """Two 1x1 convolutions of the same input as one GEMM (feather_net.h: fhip_conv_forward_siblings) -- ResNet's projection shortcut and the
+    first layer of the main branch.  Built from the two layers' geometries, filters [K][C][1][1] and biases (or None)."""
+
+    def __init__(self, pa: ConvParam, wa, ba, pb: ConvParam, wb, bb):
+        import torch
+        lib = _lib.load_library()
+        pa.AssignOutputDim()
+        pb.AssignOutputDim()
+        self.pa, self.pb = pa, pb
+        ca, cb, both = pa._c(), pb._c(), _lib.fhip_conv_param()
+        _check(lib.fhip_conv_siblings_geometry(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(both)), "fhip_conv_siblings_geometry")
+        self.both = ConvParam(output_channels=both.output_channels, input_channels=both.input_channels, input_h=both.input_h, input_w=both.input_w,
+                              kernel_h=1, kernel_w=1, stride_h=both.stride_h, stride_w=both.stride_w, pad_left=0, pad_right=0, pad_top=0, pad_bottom=0,
+                              group=1, bias_term=bool(both.bias_term), activation=0, batch=pa.batch)
+        dev = wa.device
+        w = torch.cat([wa.reshape(pa.output_channels, -1), wb.reshape(pb.output_channels, -1)]).contiguous()
+        zeros = lambda k: torch.zeros(k, dtype=torch.float32, device=dev)
+        self.bias = torch.cat([ba if ba is not None else zeros(pa.output_channels), bb if bb is not None else zeros(pb.output_channels)]) \
+            if self.both.bias_term else None
+        self.layer = ConvLayer(self.both, w, self.bias, algo=IM2COL)  # packs the stacked filters (fhip_conv_init of the stacked geometry)
+
+    def applicable(self, batch: int) -> bool:
+        ca, cb = self.pa._c(), self.pb._c()
+        return bool(_lib.load_library().fhip_conv_can_fuse_siblings(ctypes.byref(ca), IM2COL, ctypes.byref(cb), IM2COL, int(batch)))
+
+    def Forward(self, x):
+        import torch
+        n = x.shape[0]
+        ya = torch.empty((n, self.pa.output_channels, self.pa.output_h, self.pa.output_w), dtype=torch.float32, device=x.device)
+        yb = torch.empty((n, self.pb.output_channels, self.pb.output_h, self.pb.output_w), dtype=torch.float32, device=x.device)
+        ca, cb = self.pa._c(), self.pb._c()
+        _check(_lib.load_library().fhip_conv_forward_siblings(ctypes.byref(ca), ctypes.byref(cb), n, _ptr(ya), _ptr(yb), _ptr(x), _ptr(self.layer.packed),
+                                                              _ptr(self.bias) if self.bias is not None else None, _stream()), "fhip_conv_forward_siblings")
+        return ya, yb
+
+
 def stage_timing(enable: bool):
     _check(_lib.load_library().fhip_stage_timing_enable(1 if enable else 0), "fhip_stage_timing_enable")
 

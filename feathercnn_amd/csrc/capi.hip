@@ -23,6 +23,10 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
 bool winograd_can_pool(const fhip_conv_param& p);
 bool winograd_can_chain(const fhip_conv_param& p, const fhip_conv_param& next, int pool);
 bool winograd_can_fuse_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch);
+fhip_conv_param igemm_twin_geometry(const fhip_conv_param& a, const fhip_conv_param& b);
+bool igemm_twin_applicable(const fhip_conv_param& a, const fhip_conv_param& b, int batch);
+int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int batch, float* out_a, float* out_b, const float* in, const float* packed,
+                       const float* bias, hipStream_t s);
 int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_param& next, int batch, float* v, const float* input,
                               const float* first_kernel, const float* first_bias, hipStream_t s);
 int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_param& next, int batch, float* vn, const float* m, const float* bias,
@@ -288,6 +292,25 @@ int fhip_conv_forward_dw_pw(const fhip_conv_param* dw, const fhip_conv_param* pw
 {
     if (!valid_param(dw) || !valid_param(pw) || !output || !input || !dw_packed || !pw_packed || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
     return dwpw_forward(*dw, *pw, batch, output, input, dw_packed, dw_bias, pw_packed, pw_bias, (hipStream_t)stream);
+}
+
+int fhip_conv_can_fuse_siblings(const fhip_conv_param* a, int algo_a, const fhip_conv_param* b, int algo_b, int batch)
+{
+    return valid_param(a) && valid_param(b) && algo_a == FHIP_IM2COL && algo_b == FHIP_IM2COL && igemm_twin_applicable(*a, *b, batch) ? 1 : 0;
+}
+
+int fhip_conv_siblings_geometry(const fhip_conv_param* a, const fhip_conv_param* b, fhip_conv_param* both)
+{
+    if (!valid_param(a) || !valid_param(b) || !both) return fail(FHIP_E_BADARG, "bad argument");
+    *both = igemm_twin_geometry(*a, *b);
+    return FHIP_OK;
+}
+
+int fhip_conv_forward_siblings(const fhip_conv_param* a, const fhip_conv_param* b, int batch, float* output_a, float* output_b, const float* input,
+                               const float* packed_both, const float* bias_both, void* stream)
+{
+    if (!valid_param(a) || !valid_param(b) || !output_a || !output_b || !input || !packed_both || batch < 1) return fail(FHIP_E_BADARG, "bad argument");
+    return igemm_twin_forward(*a, *b, batch, output_a, output_b, input, packed_both, bias_both, (hipStream_t)stream);
 }
 
 int fhip_conv_can_chain_winograd(const fhip_conv_param* p, int algo, const fhip_conv_param* next, int next_algo, int pool)

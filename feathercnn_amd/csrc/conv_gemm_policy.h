@@ -44,6 +44,12 @@ struct ConvGemmParams
     const float* dw_w12; // [C][12]: 9 taps + 3 unused (depthwise_init's 16-byte tap rows)
     const float* dw_bias;
     int dw_stride, dw_relu;
+    // TWIN policy (two 1x1 convolutions of the same input as one GEMM, ResNet's projection shortcut + the first layer of the main
+    // branch): rows [0, twin_rows) of the concatenated filter matrix are the first layer and go to `out` ([N][twin_rows][OHW], `relu`),
+    // rows [twin_rows, K) are the second layer and go to `out2` ([N][K - twin_rows][OHW], `relu2`).  twin_rows is a multiple of the
+    // row tile, so a block writes one of the two tensors only.
+    float* out2;
+    int twin_rows, relu2;
 };
 
 constexpr int kDwFusedMaxC = 256; // channels whose taps the fused route keeps in LDS (12 floats each)
@@ -58,7 +64,7 @@ constexpr int kDwFusedMaxC = 256; // channels whose taps the fused route keeps i
 //         compulsory traffic drops from in + 2*mid + out to in + out.  (Taking the two halo columns from the neighbouring lanes with
 //         shuffles -- 6 loads instead of 9 -- was measured: faster on the 64-row tile, slower on the 128-row one: the route is bound
 //         by VALU issue next to the MFMAs, not by the address pipe.)
-template <int MODE>
+template <int MODE, bool TWIN = false>
 struct ConvGemmPolicy
 {
     using Params = ConvGemmParams;
@@ -284,10 +290,12 @@ struct ConvGemmPolicy
         unsigned valid;
         bool wide; // the 4 columns are one aligned 16-byte piece of one image
         float* part; // split-K: &partial[split][0][n4]
+        float* ptr2[TWIN ? 4 : 1]; // TWIN: &out2[img][0][rem] - twin_rows * OHW, so that row m of the GEMM is ptr2[e] + m * OHW
         __device__ Store(const Params& p, int split, int n4)
         {
             part = p.split_k > 1 ? p.partial + (size_t)split * p.K * p.Ntot + n4 : nullptr;
             valid = 0;
+            const int k_first = TWIN ? p.twin_rows : p.K; // channels of the tensor `out` points to
 #pragma unroll
             for (int e = 0; e < 4; ++e)
             {
@@ -295,7 +303,8 @@ struct ConvGemmPolicy
                 const bool ok = col < p.Ntot;
                 const int cc = ok ? col : 0;
                 const int img = cc / p.OHW, rem = cc - img * p.OHW;
-                ptr[e] = p.out + ((size_t)img * p.K) * p.OHW + rem;
+                ptr[e] = p.out + ((size_t)img * k_first) * p.OHW + rem;
+                if (TWIN) ptr2[e] = p.out2 + ((long long)img * (p.K - p.twin_rows) - p.twin_rows) * p.OHW + rem;
                 valid |= ok ? (1u << e) : 0u;
             }
             wide = (valid == 0xfu) && ((p.OHW & 3) == 0) && (ptr[3] == ptr[0] + 3);
@@ -334,6 +343,29 @@ struct ConvGemmPolicy
             v.z += b;
             v.w += b;
             const size_t moff = (size_t)m * p.OHW;
+            if (TWIN)
+            {
+                // no residual, no split-K in this form (igemm_twin_forward)
+                const bool second = m >= p.twin_rows;
+                if (second ? p.relu2 : p.relu)
+                {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                // (selected element by element: a pointer to one of the two register arrays would send both to scratch memory)
+                if (wide)
+                    *reinterpret_cast<float4*>((second ? ptr2[0] : ptr[0]) + moff) = v;
+                else
+                {
+                    if (valid & 1u) (second ? ptr2[0] : ptr[0])[moff] = v.x;
+                    if (valid & 2u) (second ? ptr2[1] : ptr[1])[moff] = v.y;
+                    if (valid & 4u) (second ? ptr2[2] : ptr[2])[moff] = v.z;
+                    if (valid & 8u) (second ? ptr2[3] : ptr[3])[moff] = v.w;
+                }
+                return;
+            }
             if (p.has_residual)
             {
                 auto res = [&](const float* o) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(o) + p.residual_delta); };

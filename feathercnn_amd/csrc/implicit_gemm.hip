@@ -454,14 +454,14 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     return FHIP_OK;
 }
 
-template <class Shape, int MODE>
+template <class Shape, int MODE, bool TWIN = false>
 static void launch(const ConvGemmParams& g0, hipStream_t s)
 {
     ConvGemmParams g = g0;
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = ceil_div(g.Ntot, Shape::BN);
     g.batches = g.split_k;
-    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.batches * g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE, TWIN>>), dim3(g.batches * g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
                        g);
 }
 
@@ -477,6 +477,8 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     g.Wt = packed;
     g.in = in;
     g.out = out;
+    g.out2 = nullptr;
+    g.twin_rows = g.relu2 = 0;
     g.bias = bias;
     g.has_residual = residual != nullptr;
     g.residual_delta = residual ? reinterpret_cast<const char*>(residual) - reinterpret_cast<const char*>(out) : 0;
@@ -607,6 +609,88 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     return FHIP_OK;
 }
 
+// ---- two 1x1 convolutions of the same input as ONE GEMM (ResNet's projection shortcut + the first layer of the main branch) ----------
+// Both read the same (strided) pixels of the same blob: their filter matrices are stacked ([Ka + Kb][C], packed by igemm_init of the
+// concatenated geometry) and gemm_mfma_kernel<ConvShapeBig, ConvGemmPolicy<MODE, TWIN>> writes rows < Ka to the first output and the
+// rest to the second, each with its own activation.  One launch instead of two, and the short grid of the main-branch layer (K = 64 ...
+// 512: 1 - 4 row tiles) rides in the long one of the shortcut instead of running the chip at 3 blocks per CU.
+fhip_conv_param igemm_twin_geometry(const fhip_conv_param& a, const fhip_conv_param& b)
+{
+    fhip_conv_param c = a;
+    c.output_channels = a.output_channels + b.output_channels;
+    c.bias_term = (a.bias_term || b.bias_term) ? 1 : 0;
+    c.activation = FHIP_ACT_NONE;
+    return c;
+}
+
+bool igemm_twin_applicable(const fhip_conv_param& a, const fhip_conv_param& b, int batch)
+{
+    auto plain1x1 = [](const fhip_conv_param& c) {
+        return c.group == 1 && c.kernel_h == 1 && c.kernel_w == 1 && !c.pad_left && !c.pad_right && !c.pad_top && !c.pad_bottom &&
+               (c.activation == FHIP_ACT_NONE || c.activation == FHIP_ACT_RELU);
+    };
+    if (!plain1x1(a) || !plain1x1(b) || batch < 1) return false;
+    if (a.input_channels != b.input_channels || a.input_h != b.input_h || a.input_w != b.input_w || a.stride_h != b.stride_h || a.stride_w != b.stride_w ||
+        a.output_h != b.output_h || a.output_w != b.output_w)
+        return false;
+    if (a.output_channels % ConvShapeBig::BM) return false; // a block writes ONE of the two tensors
+    const fhip_conv_param c = igemm_twin_geometry(a, b);
+    const long long ntot = (long long)batch * c.output_h * c.output_w;
+    if (ntot > 0x7fffff00LL || conv_narrow_n(ntot) || conv_small_m(c.output_channels) || smallc_applicable(c)) return false;
+    return !stream_profitable(c, batch) && !ip_profitable(c, batch) && igemm_split(c, batch) == 1;
+}
+
+int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int batch, float* out_a, float* out_b, const float* in, const float* packed,
+                       const float* bias, hipStream_t s)
+{
+    if (!igemm_twin_applicable(a, b, batch)) return fail(FHIP_E_UNSUPPORTED, "these two layers cannot run as one GEMM (fhip_conv_can_fuse_siblings)");
+    const fhip_conv_param p = igemm_twin_geometry(a, b);
+    if (p.bias_term && !bias) return fail(FHIP_E_BADARG, "one of the layers has a bias but the concatenated bias is NULL");
+    ConvGemmParams g;
+    g.batches = 1;
+    g.Wt = packed;
+    g.in = in;
+    g.out = out_a;
+    g.out2 = out_b;
+    g.twin_rows = a.output_channels;
+    g.bias = bias;
+    g.has_residual = 0;
+    g.residual_delta = 0;
+    g.C = p.input_channels;
+    g.K = p.output_channels;
+    g.H = p.input_h;
+    g.W = p.input_w;
+    g.OH = p.output_h;
+    g.OW = p.output_w;
+    g.SH = p.stride_h > 0 ? p.stride_h : 1;
+    g.SW = p.stride_w > 0 ? p.stride_w : 1;
+    g.PL = g.PT = 0;
+    g.KH = g.KW = 1;
+    g.Kd = g.C;
+    int kdp;
+    igemm_packed_dims(p, &kdp, &g.Kp);
+    g.Kdp = kdp;
+    g.bm = 128;
+    g.OHW = g.OH * g.OW;
+    g.HW = g.H * g.W;
+    g.KHW = 1;
+    g.Ntot = batch * g.OHW;
+    g.has_bias = p.bias_term != 0;
+    g.relu = a.activation == FHIP_ACT_RELU;
+    g.relu2 = b.activation == FHIP_ACT_RELU;
+    g.split_k = 1;
+    g.partial = nullptr;
+    g.k_tiles = kdp / kConvKTile;
+    g.m_tiles = 0;
+    g.dw_w12 = g.dw_bias = nullptr;
+    g.dw_stride = g.dw_relu = 0;
+    StageTimer tm(FHIP_STAGE_IGEMM, s);
+    if (g.SH == 1 && g.SW == 1 && (g.OHW % 4) == 0) launch<ConvShapeBig, 2, true>(g, s);
+    else launch<ConvShapeBig, 1, true>(g, s);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
 // ---- depthwise 3x3 fused into the 1x1 convolution that consumes it (MobileNet's dw -> pw pairs) -------------------------------
 // out = act_pw(W_pw * act_dw(dw3x3(in) + b_dw) + b_pw): ConvGemmPolicy<3> computes the pointwise GEMM's B operand from the depthwise
 // layer's INPUT, so the depthwise output (a tensor as large as the pair's input) is never written nor read.
@@ -644,6 +728,8 @@ int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch
     g.Wt = pw_packed;
     g.in = in;
     g.out = out;
+    g.out2 = nullptr;
+    g.twin_rows = g.relu2 = 0;
     g.bias = pw_bias;
     g.C = pw.input_channels;
     g.K = pw.output_channels;

@@ -352,6 +352,7 @@ struct Layer
     virtual const fhip_conv_param* conv_param() const { return nullptr; }
     virtual const fhip_conv_param* fused_pointwise(int*) const { return nullptr; } // the 1x1 convolution a depthwise layer absorbed
     virtual void chain_state(int* v_from_previous, int* writes_next_v) const { *v_from_previous = *writes_next_v = 0; }
+    virtual int sibling_state() const { return 0; } // 1: launches the GEMM that also computes the NEXT layer; 2: computed by the layer before
 };
 
 struct Net
@@ -442,6 +443,14 @@ struct ConvLayer : Layer
     ConvLayer* head_of = nullptr;
     ConvLayer* head = nullptr;
     DeviceVec first_raw;
+    // fusion level 2 (plan_siblings, after Reshape): this 1x1 layer and the NEXT layer of the list -- a 1x1 layer on the same bottom with
+    // the same stride: ResNet's projection shortcut and the first layer of the main branch -- run as ONE GEMM over the stacked filters
+    // (fhip_conv_forward_siblings).  `sib` (on the first layer) = the second; `sib_of` (on the second, which launches nothing) = the first.
+    ConvLayer* sib = nullptr;
+    ConvLayer* sib_of = nullptr;
+    ConvLayer* sib_packed_for = nullptr; // the partner sib_packed / sib_bias were built with
+    DeviceVec sib_packed, sib_bias;
+    bool sib_has_bias = false;
     bool first_candidate() const
     {
         return p.kernel_h == 3 && p.kernel_w == 3 && p.stride_h == 1 && p.stride_w == 1 && p.group == 1 && p.input_channels >= 2 && p.input_channels <= 4 && p.pad_left == 1 &&
@@ -542,6 +551,50 @@ struct ConvLayer : Layer
         if (rc) return rc;
         return fhip_conv_get_buffer_size(&p, algo_, b->n, &buffer_bytes, &packed_bytes);
     }
+    // filters and bias with the folded BatchNorm / Scale (fusion level 2) applied
+    void folded(std::vector<float>& w, std::vector<float>& b) const
+    {
+        w = w_host;
+        b = b_host;
+        if (post_mul.empty()) return;
+        const int K = p.output_channels;
+        const size_t per = w.size() / K;
+        if (b.empty()) b.assign(K, 0.f);
+        for (int k = 0; k < K; ++k)
+        {
+            for (size_t i = 0; i < per; ++i) w[k * per + i] *= post_mul[k];
+            b[k] = b[k] * post_mul[k] + post_add[k];
+        }
+    }
+    int init_siblings(hipStream_t s)
+    {
+        std::vector<float> wa, ba, wb, bb;
+        folded(wa, ba);
+        sib->folded(wb, bb);
+        fhip_conv_param pa = p, pb = sib->p, both;
+        pa.bias_term = ba.empty() ? 0 : 1;
+        pb.bias_term = bb.empty() ? 0 : 1;
+        int rc = fhip_conv_siblings_geometry(&pa, &pb, &both);
+        if (rc) return rc;
+        wa.insert(wa.end(), wb.begin(), wb.end());
+        sib_has_bias = both.bias_term != 0;
+        if (sib_has_bias)
+        {
+            if (ba.empty()) ba.assign(p.output_channels, 0.f);
+            if (bb.empty()) bb.assign(sib->p.output_channels, 0.f);
+            ba.insert(ba.end(), bb.begin(), bb.end());
+            if ((rc = sib_bias.upload(ba.data(), ba.size(), s))) return rc;
+        }
+        size_t bytes = 0, pk = 0;
+        if ((rc = fhip_conv_get_buffer_size(&both, FHIP_IM2COL, bottoms[0]->n, &bytes, &pk))) return rc;
+        DeviceVec raw;
+        if ((rc = raw.upload(wa.data(), wa.size(), s))) return rc;
+        if ((rc = sib_packed.resize(pk))) return rc;
+        if ((rc = fhip_conv_init(&both, FHIP_IM2COL, sib_packed.d, raw.d, s))) return rc;
+        FHIP_CHECK_HIP(hipStreamSynchronize(s)); // `raw` goes out of scope
+        sib_packed_for = sib;
+        return 0;
+    }
     int Init(hipStream_t s) override
     {
         if (pw)
@@ -549,20 +602,15 @@ struct ConvLayer : Layer
             const int rc = pw->Init(s);
             if (rc) return rc;
         }
-        if (inited_algo == algo_ && packed.bytes == packed_bytes) return 0;
-        const int K = p.output_channels;
-        std::vector<float> w = w_host, b = b_host;
-        if (!post_mul.empty())
+        if (sib && sib_packed_for != sib)
         {
-            const size_t per = w.size() / K;
-            if (b.empty()) b.assign(K, 0.f);
-            for (int k = 0; k < K; ++k)
-            {
-                for (size_t i = 0; i < per; ++i) w[k * per + i] *= post_mul[k];
-                b[k] = b[k] * post_mul[k] + post_add[k];
-            }
-            p.bias_term = 1;
+            const int rc = init_siblings(s);
+            if (rc) return rc;
         }
+        if (inited_algo == algo_ && packed.bytes == packed_bytes) return 0;
+        std::vector<float> w, b;
+        folded(w, b);
+        if (!post_mul.empty()) p.bias_term = 1;
         DeviceVec raw;
         int rc = raw.upload(w.data(), w.size(), s);
         if (rc) return rc;
@@ -584,6 +632,10 @@ struct ConvLayer : Layer
     {
         const float* b = p.bias_term ? bias.d : nullptr;
         if (head_of) return 0; // computed inside head_of's input transform
+        if (sib_of) return 0;  // computed by the layer before, in the same GEMM
+        if (sib)
+            return fhip_conv_forward_siblings(&p, &sib->p, bottoms[0]->n, tops[0]->data, sib->tops[0]->data, bottoms[0]->data, sib_packed.d,
+                                              sib_has_bias ? sib_bias.d : nullptr, s);
         if (pw)
         {
             const float* pb = pw->p.bias_term ? pw->bias.d : nullptr;
@@ -663,7 +715,7 @@ struct ConvLayer : Layer
     }
     size_t weight_bytes() const override
     {
-        return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + first_raw.bytes + (pw ? pw->weight_bytes() : 0);
+        return packed.bytes + bias.bytes + pre_pool.bytes + mid.bytes + first_raw.bytes + sib_packed.bytes + sib_bias.bytes + (pw ? pw->weight_bytes() : 0);
     }
     const fhip_conv_param* fused_pointwise(int* one_kernel) const override
     {
@@ -673,6 +725,7 @@ struct ConvLayer : Layer
     size_t arena_bytes() const override { return std::max(buffer_bytes, chain_bytes); }
     const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
+    int sibling_state() const override { return sib ? 1 : sib_of ? 2 : 0; }
     void chain_state(int* v_from_previous, int* writes_next_v) const override
     {
         *v_from_previous = head ? 2 : chain_in ? 1 : 0;
@@ -1277,6 +1330,7 @@ static int plan_concurrency(Net& net)
     {
         Layer* l = net.layers[i].get();
         if ((l->type != "Convolution" && l->type != "ConvolutionDepthWise") || l->arena_bytes() != 0 || l->tops.size() != 1) continue;
+        if (l->sibling_state()) continue; // writes (or is written with) the top of its neighbour: stays on the net's stream
         size_t consumer = 0;
         int uses = 0;
         for (size_t j = i + 1; j < L; ++j)
@@ -1389,6 +1443,38 @@ static int plan_chains(Net& net)
     return 0;
 }
 
+// Fusion level 2, after Reshape (needs routes, shapes and the batch): two 1x1 convolutions that follow each other in the layer list and
+// read the same blob with the same stride run as one GEMM (fhip_conv_forward_siblings).  ResNet-50: res3a / res4a / res5a branch1 + branch2a.
+static int plan_siblings(Net& net)
+{
+    const size_t L = net.layers.size();
+    std::vector<ConvLayer*> conv(L, nullptr);
+    for (size_t i = 0; i < L; ++i)
+        if (net.layers[i]->type == "Convolution")
+        {
+            conv[i] = static_cast<ConvLayer*>(net.layers[i].get());
+            conv[i]->sib = conv[i]->sib_of = nullptr;
+        }
+    if (net.fusion < 2) return 0;
+    auto root = [](const Blob* b) { return b->alias ? b->alias : b; };
+    auto plain = [](const ConvLayer* c) {
+        return c && !c->pw && !c->residual && !c->fuse_pool && !c->chain_in && !c->chain_next && !c->head && !c->head_of && !c->sib && !c->sib_of &&
+               c->algo_ == FHIP_IM2COL && c->tops.size() == 1 && c->bottoms.size() == 1;
+    };
+    for (size_t i = 0; i + 1 < L; ++i)
+    {
+        ConvLayer *a = conv[i], *b = conv[i + 1];
+        if (!plain(a) || !plain(b) || root(a->bottoms[0]) != root(b->bottoms[0]) || a->tops[0] == b->tops[0]) continue;
+        // both layers on the 128-row tile when alone (a 64-row layer -- ResNet's res2a_branch2a -- is faster on its own 64 x 128 tile:
+        // tools/sibling_bench.py 116 vs 126 us for the pair)
+        if (a->p.output_channels <= 64 || b->p.output_channels <= 64) continue;
+        if (!fhip_conv_can_fuse_siblings(&a->p, a->algo_, &b->p, b->algo_, a->bottoms[0]->n)) continue;
+        a->sib = b;
+        b->sib_of = a;
+    }
+    return 0;
+}
+
 static int reshape_all(Net& net)
 {
     net.drop_graph();
@@ -1399,8 +1485,9 @@ static int reshape_all(Net& net)
         if (rc) return rc;
     }
     {
-        const int rc = plan_chains(net);
+        int rc = plan_chains(net);
         if (rc) return rc;
+        if ((rc = plan_siblings(net))) return rc;
     }
     for (auto& l : net.layers) need = std::max(need, l->arena_bytes());
     // one scratch arena shared by every layer = max over layers (mempool.cpp:88-92)
@@ -1853,6 +1940,14 @@ int fhip_net_layer_fused_pointwise(fhip_net* n, int index, fhip_conv_param* para
     const fhip_conv_param* cp = n->impl.layers[index]->fused_pointwise(one_kernel);
     if (!cp) return fail(FHIP_E_BADARG, "no pointwise convolution was absorbed into this layer");
     *param = *cp;
+    return FHIP_OK;
+}
+
+int fhip_net_layer_sibling(fhip_net* n, int index, int* state)
+{
+    NET_GUARD(n);
+    if (index < 0 || index >= (int)n->impl.layers.size() || !state) return fail(FHIP_E_BADARG, "layer index out of range");
+    *state = n->impl.layers[index]->sibling_state();
     return FHIP_OK;
 }
 

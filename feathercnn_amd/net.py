@@ -134,6 +134,15 @@ class Net:
                 out[i] = (p, bool(one.value))
         return out
 
+    def siblings(self):
+        """{layer index: 1 | 2} -- 1: this 1x1 convolution's launch also computes the next layer (fhip_conv_forward_siblings), 2: that next layer."""
+        out = {}
+        for i in range(self._lib.fhip_net_layer_count(self._h)):
+            st = ctypes.c_int()
+            if self._lib.fhip_net_layer_sibling(self._h, i, ctypes.byref(st)) == 0 and st.value:
+                out[i] = st.value
+        return out
+
     def chains(self, raw=False):
         """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3).
         raw=True keeps the library's values: 2 marks the pair "first layer computed inside the next layer's input transform"."""

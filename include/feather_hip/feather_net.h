@@ -105,6 +105,21 @@ FHIP_API int fhip_conv_forward_chained(const fhip_conv_param* param, int batch, 
 FHIP_API int fhip_winograd_f63_output_to_next_input(const fhip_conv_param* param, const fhip_conv_param* next, int batch, float* v_next,
                                                     const float* m, const float* bias, int pool, void* stream);
 
+/* Two 1x1 convolutions of the SAME input as one GEMM: ResNet's projection shortcut (res3a_branch1, 256 -> 512, stride 2) and the first
+ * layer of the main branch beside it (res3a_branch2a, 256 -> 128, stride 2) read the same pixels of the same blob; in the reference they are
+ * two ConvLayer::Forward calls (conv_layer.h:141-150; packed SGEMM avx/sgemm.cpp:377-433).  Here their filter matrices are stacked
+ * ([Ka + Kb][C]) and one launch writes rows < Ka to `output_a` and the rest to `output_b`, each with its own activation: the short grid of
+ * the main-branch layer (1 - 4 row tiles) rides in the long one of the shortcut instead of running the chip at 3 blocks per CU.
+ *   fhip_conv_can_fuse_siblings: 1 when the pair qualifies at this batch (both IM2COL 1x1 / pad 0 / group 1 on the same input geometry and
+ *     stride, Ka a multiple of 128, the combined grid needs no split-K and takes the LDS-tiled route).
+ *   fhip_conv_siblings_geometry fills the geometry of the stacked layer: run fhip_conv_get_buffer_size / fhip_conv_init (algo IM2COL) on
+ *     it with the stacked filters to get `packed_both`; `bias_both` = the two biases one after the other (zeros for a layer without one).
+ *   fhip_conv_forward_siblings: the launch.  Results equal the two layers run on the LDS-tiled route (same tile, same k order). */
+FHIP_API int fhip_conv_can_fuse_siblings(const fhip_conv_param* a, int algo_a, const fhip_conv_param* b, int algo_b, int batch);
+FHIP_API int fhip_conv_siblings_geometry(const fhip_conv_param* a, const fhip_conv_param* b, fhip_conv_param* both);
+FHIP_API int fhip_conv_forward_siblings(const fhip_conv_param* a, const fhip_conv_param* b, int batch, float* output_a, float* output_b,
+                                        const float* input, const float* packed_both, const float* bias_both, void* stream);
+
 /* A net's first convolution inside the Winograd layer behind it.  `first` is a 3x3 / stride-1 / pad-1 convolution with 2 .. 4 input
  * channels (VGG-16's conv1_1: ConvLayer::Forward through the im2col + SGEMM route, conv_layer.h:141-150, avx/booster.cpp:108-160) whose
  * only consumer `next` is a 3x3 / stride-1 / pad-1 WINOGRADF63 layer.  Its output is as large as the largest tensor of the net and holds
@@ -132,8 +147,9 @@ FHIP_API int fhip_net_set_stream(fhip_net* net, void* stream);
  *   0: none -- every layer of the file runs and every blob can be extracted, like the reference as shipped.
  *   1 (default): the TryFuse pass the reference declares but never calls (layer.cpp:82-101): Conv+ReLU, InnerProduct+ReLU,
  *      BatchNorm+Scale(+ReLU), Scale+ReLU, Eltwise+ReLU.
- *   2: + BatchNorm / Scale folded into the convolution before them, Conv + 2x2 max pooling, Conv + Eltwise SUM (+ReLU), and a 3x3
- *      depthwise layer + the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw where the pair qualifies).
+ *   2: + BatchNorm / Scale folded into the convolution before them, Conv + 2x2 max pooling, Conv + Eltwise SUM (+ReLU), a 3x3
+ *      depthwise layer + the 1x1 convolution behind it as one layer (fhip_conv_forward_dw_pw where the pair qualifies), and two 1x1
+ *      convolutions of the same input that follow each other as one GEMM (fhip_conv_forward_siblings; both blobs keep their storage).
  *   3: + runs of Winograd layers chained (fhip_conv_forward_chained): the blob between two chained layers has a shape but no storage;
  *      a first layer (3x3 / stride 1 / pad 1, 2 .. 4 input channels) in front of a Winograd layer is computed inside that layer's input
  *      transform (fhip_winograd_f63_input_from_first): its top has no storage either.
@@ -207,6 +223,9 @@ FHIP_API int fhip_net_layer_fused_pointwise(fhip_net* net, int index, fhip_conv_
  * is 2 for the pair "first layer computed inside the next layer's input transform" (fhip_winograd_f63_input_from_first): writes_next_v =
  * 2 on the first layer (it launches nothing), v_from_previous = 2 on the Winograd layer behind it. */
 FHIP_API int fhip_net_layer_chain(fhip_net* net, int index, int* v_from_previous, int* writes_next_v);
+/* Fusion level 2: *state = 1 when this 1x1 convolution's launch also computes the NEXT layer of the list (a 1x1 convolution of the same
+ * input: fhip_conv_forward_siblings), 2 when this layer is that next one (it launches nothing), 0 otherwise. */
+FHIP_API int fhip_net_layer_sibling(fhip_net* net, int index, int* state);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

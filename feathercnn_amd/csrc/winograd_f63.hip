@@ -635,7 +635,10 @@ int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_para
     q.LDW = 6 * q.TX + 4;
     q.rows = 6 * std::min(pl.tiles_y, (q.TX + kFirstTiles - 2) / q.TX + 1) + 4;
     const size_t lds = (size_t)first.input_channels * q.rows * q.LDW * sizeof(float);
-    if (lds <= 64 * 1024 && q.LDW <= 256 && (long long)q.bpi * batch <= 0x7fffffffLL) // 128 float2 columns: one per thread pair
+    // the staged form gives every image blocks of its own: below 3/4 full lanes (small planes: 14 x 14 has 9 tiles) the direct form,
+    // whose lanes run across images, is the better one
+    const bool lanes_full = 4 * q.T >= 3 * q.bpi * kFirstTiles;
+    if (lanes_full && lds <= 64 * 1024 && q.LDW <= 256 && (long long)q.bpi * batch <= 0x7fffffffLL) // 128 float2 columns: one per thread pair
     {
         const dim3 grid((unsigned)(q.bpi * batch), (unsigned)ceil_div(q.K, kFirstCpb));
         switch (first.input_channels)

@@ -47,7 +47,8 @@ CASES = [
     ("one_tile", 5, 3, 6, 6, 4, True, True, False),
     ("tiny", 2, 3, 3, 4, 3, True, True, False),
     ("wide_rows_direct_form", 1, 4, 14, 1200, 6, True, True, False),  # 4 x 22 x 1210 floats do not fit the LDS: the L1 form
-    ("many_tile_rows_per_block", 2, 3, 40, 14, 18, True, True, False),  # TX = 3: a block of 64 tiles spans the whole image
+    ("small_plane_direct_form", 2, 3, 40, 14, 18, True, True, False),  # 21 tiles per image: lanes run across images (direct form)
+    ("two_blocks_per_image", 3, 3, 64, 64, 24, True, True, False),  # 121 tiles: blocks of 64 + 57 tiles, 6 - 7 tile rows each, 2 channel groups
 ]
 
 

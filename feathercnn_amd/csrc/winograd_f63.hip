@@ -378,8 +378,9 @@ struct WinoChain
     int LDW, LDH;     // LDS plane: (AH + 2 rows) x LDW floats, 2 border columns left, >= 2 right
 };
 
+// (the pooled form fits 96 registers: 5 waves per SIMD let a third 6-wave block of the 112 -> 56 px boundary on a CU, 116.6 -> 114.2 us)
 template <bool HAS_BIAS, bool RELU, bool POOL>
-__global__ __launch_bounds__(512) void wino_chain_kernel(float* __restrict__ Vn, const float* __restrict__ M, const float* __restrict__ bias,
+__global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __restrict__ Vn, const float* __restrict__ M, const float* __restrict__ bias,
                                                         const WinoChain g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[]; // [ppb][LDH][LDW]

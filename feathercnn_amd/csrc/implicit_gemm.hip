@@ -202,6 +202,7 @@ struct SmallCParams
     int C, K, H, W, OH, OW, S, PL, PT, KH, KW, Kd, Kp, N;
     int kd2;           // MFMA k-steps: ceil(Kd / 2) rounded up to a multiple of 4 (the extra rows meet zero weights)
     int PH, PW, patch; // patch rows, columns, floats
+    int patch_alloc;   // LDS floats reserved for the patch (patch rounded up to 64)
     int tiles_x, tiles_y;
     long long tiles;
     int has_bias, relu;
@@ -216,10 +217,13 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
     constexpr int BM = 32 * TM, EPI_LD = 36;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;                                        // [2*kd2][BM]
-    float* const patch = As + (size_t)2 * q.kd2 * BM;              // [patch]
-    int* const ptab = reinterpret_cast<int*>(patch + kSmallCMaxPatch); // [patch] packed (c << 16 | r << 8 | x)
-    int* const koff = ptab + kSmallCMaxPatch;                      // [2][kd2]: koff[h*kd2 + kp] = patch offset of reduction row 2*kp + h
+    float* const patch = As + (size_t)2 * q.kd2 * BM;              // [patch_alloc]
+    int* const koff = reinterpret_cast<int*>(patch + q.patch_alloc); // [2][kd2]: koff[h*kd2 + kp] = patch offset of reduction row 2*kp + h
     float* const scr = reinterpret_cast<float*>(koff + 2 * q.kd2) + 0; // [4][32][EPI_LD]
+    // the patch decode table (c << 16 | r << 8 | x per patch element) is read ONCE, before the tile loop: it lives in the epilogue's
+    // transpose buffer (PASSES * 256 <= 2816 ints of its 4608 floats; two barriers of the first tile separate the last read from the
+    // first epilogue write) -- 11 KB of LDS per block that buy a fourth / fifth resident block
+    int* const ptab = reinterpret_cast<int*>(scr);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     // ---- once per block: weights, reduction-row table, patch decode table
@@ -419,8 +423,12 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     q.has_bias = p.bias_term != 0;
     q.relu = relu;
     const int tm = q.K <= 32 ? 1 : 2, bm = 32 * tm;
-    const size_t lds = ((size_t)2 * q.kd2 * bm + kSmallCMaxPatch + 4 * 32 * 36) * sizeof(float) + ((size_t)kSmallCMaxPatch + 2 * q.kd2) * sizeof(int);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+    q.patch_alloc = round_up(q.patch, 64);
+    const size_t lds = ((size_t)2 * q.kd2 * bm + q.patch_alloc + 4 * 32 * 36) * sizeof(float) + ((size_t)2 * q.kd2) * sizeof(int);
+    // resident blocks per CU (the grid is persistent): as many as the LDS takes, up to 6 at stride 1 and 4 at stride 2 (tools/conv1_bench.py,
+    // same box: VGG conv1_1 b32 137 / 126 / 119 / 118 us with 3 / 4 / 5 / 6, MobileNet conv1 b256 191 / 183 / 191 / 191; an XCD-contiguous
+    // tile order changed nothing)
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(q.S == 1 ? 6 : 4, (size_t)(160 * 1024) / (lds + 512)));
     const int grid = (int)std::min<long long>(q.tiles, (long long)device_compute_units() * per_cu);
     const int passes = ceil_div(q.patch, 256);
 #define FHIP_SMALLC_LAUNCH(TM_, P_)                                                                                               \

@@ -491,6 +491,8 @@ struct ConvLayer : Layer
     int LoadWeights(ModelBin& mb) override
     {
         const size_t wsize = (size_t)p.input_channels * p.output_channels * p.kernel_h * p.kernel_w;
+        inited_algo = -2; // new weights: every packed form is rebuilt at the next Init
+        sib_packed_for = nullptr;
         int rc = mb.load(wsize, 0, w_host);
         if (rc) return rc;
         if (p.bias_term)

@@ -7,7 +7,8 @@
 // MEASURED (tools/g4_bench.hip, synthetic operands, VGG-16 conv1_2 b32, 24.2 GF): 478 us with 16 tiles per wave (232 VGPRs, 2 waves per
 // SIMD: 51 TF = 0.32 of the MFMA peak), 540 us with 32 tiles per wave (one wave per SIMD); an eight-slot operand ring at one wave per SIMD
 // (slot j re-requested for the next row of frequency points as soon as its MFMAs are issued) 906 us -- hipcc sinks the ring's loads to
-// their uses, it would take stream_gemm.h's inline-asm loads and counted waits.  The tile GEMM + chained transform it would replace take
+// their uses; with stream_gemm.h's inline-asm loads and counted waits (4 slots, scalar bases) 519 us: above 256 registers the 144
+// accumulators move to AGPRs and every update pays accvgpr moves.  The tile GEMM + chained transform it would replace take
 // 312 + 223 = 535 us, and it would add an input transform for conv2_1 (~60 us): no gain as it stands.  Every wave re-streams its share of
 // U (1 MB per block of 16 tiles, 2.9 GB of L2 -> CU traffic per launch) and a frequency point is 512 clk of matrix work against ~2.9 k clk
 // of L2 latency: the form needs either the ring or operand sharing through LDS (barriers per frequency point).  Not pursued.

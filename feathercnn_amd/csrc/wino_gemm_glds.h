@@ -226,6 +226,12 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
 }
 
 // does the 96-column tile pad fewer columns than the 64-column one?  (pure function of the column count)
-inline bool wino_gemm_prefers_96(int columns) { return ceil_div(columns, 96) * 96 < ceil_div(columns, 64) * 64; }
+// ... or, with neither padding, are the columns so few that whole 96-column tiles give one balanced round of fewer, larger blocks?
+// (ResNet-50 b64's 14-pixel 3x3 layers: P = 576 = 9 x 64 = 6 x 96 -- 1152 blocks, 4.5 per CU, against 768, 3 per CU: 51.3 -> 47.8 us in
+// tools/gemm_bench.hip (GEMM_RESNET=1 GEMM_96=1); P = 1600 and P = 256 stay faster on 64 columns)
+inline bool wino_gemm_prefers_96(int columns)
+{
+    return ceil_div(columns, 96) * 96 < ceil_div(columns, 64) * 64 || (columns % 96 == 0 && columns <= 576);
+}
 
 } // namespace fhip

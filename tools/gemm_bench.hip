@@ -133,7 +133,12 @@ int main(int argc, char** argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
     // the Winograd tile-GEMM shapes of VGG-16 at batch 32 (C, K, P)
-    const Case cases[] = {{64, 64, 46208}, {64, 128, 11552}, {128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}};
+    // (GEMM_RESNET: ResNet-50's 3x3 layers at batch 64 instead)
+    const Case vgg[] = {{64, 64, 46208}, {64, 128, 11552}, {128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}};
+    const Case resnet[] = {{128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {256, 256, 576}, {512, 512, 256}};
+    const Case* cases_p = getenv("GEMM_RESNET") ? resnet : vgg;
+    Case cases[8];
+    for (int i = 0; i < 8; ++i) cases[i] = cases_p[i];
     size_t maxU = 0, maxV = 0, maxM = 0;
     for (auto& c : cases)
     {

@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay per step")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes for the CPU baseline (default: one per host core, bounded by free memory)")
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
+    ap.add_argument("--manifest-out", default="", help="write what ran (tree head, source fingerprint, per-net batch / replicas, fusion level) here: "
+                    "tools/profile.sh hands it to tools/summarize_prof.py, which stamps traffic.json with it")
     ap.add_argument("--mode", default="net", choices=["net", "convstack"])
     ap.add_argument("--no-overlap", action="store_true", help="net mode: keep every layer on one stream (no branch concurrency)")
     ap.add_argument("--reference-selection", action="store_true",
@@ -225,16 +227,28 @@ TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "
                    "wino_input_transform_kernel": ("wino_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
 
 
-def attach_traffic(net_name, roofs):
+def _round_of(path):
+    """profiles/r12_vgg16/traffic.json -> 12 (numeric, so r10 sorts after r9)."""
+    import re
+    m = re.match(r"r(\d+)_", os.path.basename(os.path.dirname(path)))
+    return int(m.group(1)) if m else -1
+
+
+def attach_traffic(net_name, roofs, batch=None, sub_batches=1, fusion=None):
     """roofline.traffic: HBM bytes per launch of the row's kernels from the rocprofv3 PMC passes of THIS command (2 * FETCH_SIZE + WRITE_SIZE,
     separate --pmc passes, the gfx950 correction of MI355X_MICROARCH.md; tools/profile.sh + tools/summarize_prof.py).  PMC counters cannot be
-    read inside the benchmark process, so the figure comes from the digest committed under profiles/ (newest round that has one for this net);
-    null when there is none.  Launch-weighted mean over the kernels of the row; `achieved` and `frac` stay live measurements."""
+    read inside the benchmark process, so the figure comes from the digest committed under profiles/ (newest round that has one for this net)
+    -- and ONLY when that digest describes the tree that is running: its `_meta.source_fingerprint` (sha256 over the kernel and runtime
+    sources, feathercnn_amd/provenance.py) must equal the live one and its profiled batch / fusion level the measured ones.  Otherwise
+    traffic stays null and `traffic_stale` says why.  `traffic_head` = git commit of the running tree (the digest is valid for it because
+    the fingerprints are equal), `traffic_profiled_at` = the commit the profile was taken on.  Launch-weighted mean over the kernels of
+    the row; `achieved` and `frac` stay live measurements."""
     import glob
-    # newest round first; within a round the single-stream profile (what the per-kernel attribution runs) before the replica one
+    from feathercnn_amd import provenance
+    # newest round first (numerically); within a round the single-stream profile (what the per-kernel attribution runs) before the replica one
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{net_name}", "traffic.json")) +
                    glob.glob(os.path.join(ROOT, "profiles", f"r*_{net_name}_single_stream", "traffic.json")),
-                   key=lambda q: (os.path.basename(os.path.dirname(q))[:3], q.endswith("_single_stream/traffic.json")))
+                   key=lambda q: (_round_of(q), q.endswith("_single_stream/traffic.json")))
     if not cands:
         return
     path = cands[-1]
@@ -242,21 +256,44 @@ def attach_traffic(net_name, roofs):
         dig = json.load(open(path))
     except (OSError, ValueError):
         return
+    meta = dig.get("_meta") or {}
+    here = provenance.tree_head()
+    stale = None
+    if not meta.get("source_fingerprint"):
+        stale = "the digest carries no source fingerprint (profiled before round 4)"
+    elif meta["source_fingerprint"] != here["source_fingerprint"]:
+        stale = f"profiled on sources {meta['source_fingerprint']} (commit {meta.get('git_head')}), running {here['source_fingerprint']}"
+    else:
+        prof = (meta.get("nets") or {}).get(net_name) or {}
+        if batch is not None and prof.get("per_gpu_batch") not in (None, batch):
+            stale = f"profiled at batch {prof.get('per_gpu_batch')}, measured at {batch}"
+        elif fusion is not None and meta.get("fusion") not in (None, fusion):
+            stale = f"profiled at fusion level {meta.get('fusion')}, measured at {fusion}"
+    src = os.path.relpath(path, ROOT)
     for r in roofs:
         pats = next((v for k, v in TRAFFIC_KERNELS.items() if r["kernel"].startswith(k)), None)
         if not pats:
             continue
-        rows = [v for k, v in dig.items() if any(q in k for q in pats)]
+        if stale:
+            r["traffic"] = None
+            r["traffic_stale"] = f"{src}: {stale}"
+            continue
+        rows = [v for k, v in dig.items() if k != "_meta" and any(q in k for q in pats)]
         n = sum(v["launches_profiled"] for v in rows)
         if n:
             r["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in rows) / n)
             r["traffic_unit"] = "HBM bytes per launch (launch-weighted mean over the row's kernels)"
-            r["traffic_source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2*FETCH + WRITE)"
+            r["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2*FETCH + WRITE)"
+            r["traffic_head"] = here["git_head"]
+            r["traffic_profiled_at"] = meta.get("git_head")
+            r["traffic_fingerprint"] = here["source_fingerprint"]
 
 
 TRAFFIC_NOTE = ("traffic (HBM bytes per launch from rocprofv3 PMC passes) cannot be collected inside this process: it is read from the digest of "
-                "the same command committed under profiles/ (traffic_source); the per-round counters of "
-                "this same command are committed under profiles/ (tools/profile.sh)")
+                "the same command committed under profiles/ (traffic_source) and attached only when the digest's source fingerprint "
+                "(feathercnn_amd/provenance.py: sha256 over the kernel + runtime sources) equals the running tree's and the profiled batch / "
+                "fusion level are the measured ones -- otherwise traffic is null and traffic_stale says why; traffic_head = commit of the running "
+                "tree, traffic_profiled_at = commit the counters were collected on")
 
 
 def attribute(net, reps):
@@ -497,7 +534,7 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
             net.Forward()
             torch.cuda.synchronize()
         att = attribute(net, max(3, min(steps, 5)))
-        attach_traffic(net_name, att["rooflines"])
+        attach_traffic(net_name, att["rooflines"], batch=nb, sub_batches=replicas, fusion=a.fusion)
         n_model_layers = len(netcheck_layers(p))
         res["workload"] = (f"{net_name} whole net ({n_model_layers} layers in the model file, {len(net.layers())} after fusion level {a.fusion}), "
                            f"batch {nb} per GPU" + (f" as {replicas} concurrent sub-batch replicas of the net (fhip_net_set_sub_batches)" if replicas > 1 else "")
@@ -511,6 +548,49 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     del net, x
     torch.cuda.empty_cache()
     return res, model
+
+
+def shard_check(net_name, model, a, env):
+    """N > 1 only: the property the batch shard rests on (the reference runs one image at a time, src/layers/conv_layer.h:107, so images are
+    independent).  Every rank draws the SAME seeded global batch (2 * world + 1 images: ragged shares), runs its shard_range of it through
+    its own net (weights from the broadcast), the shards are gathered on rank 0 and compared with rank 0's run of the whole batch.
+    -> {"global_batch", "max_norm_err", "ok"} on rank 0 (not timed, not part of `value`)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from feathercnn_amd.net import Net
+    from feathercnn_amd.shard import shard_range
+    dev, rank, world = env["dev"], env["rank"], env["world"]
+    p, b, in_name, out_name = model
+    G = 2 * world + 1
+    x_all = np.random.default_rng(97).uniform(-1, 1, (G, 3, 224, 224)).astype(np.float32)
+
+    def run(x):
+        n_ = Net(fusion=a.fusion, graph=False, tuned=not a.reference_selection, concurrency=not a.no_overlap)
+        n_.LoadParam(p)
+        n_.LoadWeights(b)
+        n_.FeedInput(in_name, torch.from_numpy(x).to(dev))
+        n_.Forward()
+        y = np.array(n_.Extract(out_name), dtype=np.float32).reshape(x.shape[0], -1)
+        n_.close()
+        return y
+    lo, hi = shard_range(G, rank, world)
+    mine = run(x_all[lo:hi])
+    width = mine.shape[1]
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # gloo (the one-GPU rehearsal) gathers host tensors
+    pad = torch.zeros((G // world + 1, width), dtype=torch.float32, device=cdev)
+    pad[:hi - lo] = torch.from_numpy(mine).to(cdev)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    if rank != 0:
+        return None
+    whole = run(x_all)
+    got = np.concatenate([parts[r][:shard_range(G, r, world)[1] - shard_range(G, r, world)[0]].cpu().numpy() for r in range(world)])
+    err = float(np.abs(got - whole).max() / max(float(np.abs(whole).max()), 1e-30))
+    return {"net": net_name, "global_batch": G, "shares": [shard_range(G, r, world)[1] - shard_range(G, r, world)[0] for r in range(world)],
+            "max_norm_err": err, "ok": bool(err <= 1e-5),
+            "what": "every rank's shard of one seeded batch, gathered, vs rank 0's run of the whole batch (same broadcast weights)"}
 
 
 def netcheck_layers(param_text):
@@ -707,7 +787,10 @@ def main():
                 # configs[4]: ResNet-50, 512 images in total sharded over the ranks (strong), plus its weak point (64 per GPU)
                 extras["resnet50_global512"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, global_batch=512)
                 extras["resnet50"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, detail=False)
+    shard_ok = None
     if world > 1:
+        if a.mode == "net":
+            shard_ok = shard_check(head_net, model, a, env)
         dist.barrier()
 
     if rank == 0:
@@ -724,6 +807,8 @@ def main():
         }
         if affinity is not None:
             res["config"]["rank0_cpu_affinity"] = affinity
+        if shard_ok is not None:
+            res["shard_check"] = shard_ok
         table = head.pop("table", [])
         cpu_fn = head.pop("cpu_baseline_fn", None)
         for k in ("stage_ms_per_step", "layer_type_ms_per_step", "conv_tflops_direct", "conv_gflops_per_s_direct", "device_memory", "weight_broadcast"):
@@ -759,6 +844,13 @@ def main():
                     res["cpu_baseline"] = net_cpu_baseline(head_net, model, a.cpu_procs)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        from feathercnn_amd import provenance
+        res["tree"] = provenance.tree_head()
+        if a.manifest_out:
+            os.makedirs(os.path.dirname(os.path.abspath(a.manifest_out)), exist_ok=True)
+            with open(a.manifest_out, "w") as f:
+                json.dump(dict(res["tree"], fusion=a.fusion, argv=sys.argv[1:],
+                               nets={k: {q: v[q] for q in ("per_gpu_batch", "sub_batches", "global_batch") if q in v} for k, v in nets_out.items()}), f, indent=1)
         if a.layers_out:
             os.makedirs(os.path.dirname(os.path.abspath(a.layers_out)), exist_ok=True)
             with open(a.layers_out, "w") as f:

@@ -52,15 +52,14 @@ static bool stream_profitable(const fhip_conv_param& p, int batch)
 // ---- the weight-streaming InnerProduct route (ip_stream.h) -----------------------------------------------------------------------
 // eligible: a 1x1 convolution over a 1x1 image (what feather::InnerProductLayer is on the device) -- decides the packed size;
 // profitable: at most one MFMA column tile of images and a weight matrix worth streaming (VGG-16's fc6 / fc7 / fc8 at batch <= 32).
+// (the channel thresholds are geometry, not batch: they sit in ip_eligible so that small InnerProduct / 1x1 layers, which never take the
+// route at any batch, do not carry a second copy of their weights -- ADVICE r03)
 static bool ip_eligible(const fhip_conv_param& p)
 {
     return p.group == 1 && p.kernel_h == 1 && p.kernel_w == 1 && p.input_h == 1 && p.input_w == 1 && p.output_h == 1 && p.output_w == 1 &&
-           p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;
+           p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0 && p.input_channels >= 1024 && p.output_channels >= 256;
 }
-static bool ip_profitable(const fhip_conv_param& p, int batch)
-{
-    return ip_eligible(p) && batch >= 1 && batch <= 32 && p.input_channels >= 1024 && p.output_channels >= 256;
-}
+static bool ip_profitable(const fhip_conv_param& p, int batch) { return ip_eligible(p) && batch >= 1 && batch <= 32; }
 static int ip_kg(const fhip_conv_param& p) { return ceil_div(p.output_channels, 32); }
 static int ip_kq(const fhip_conv_param& p) { return ceil_div(p.input_channels, 8); }
 static size_t ip_packed_floats(const fhip_conv_param& p) { return (size_t)ip_kg(p) * ip_kq(p) * 256; }

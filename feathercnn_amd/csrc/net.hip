@@ -1474,6 +1474,15 @@ static int plan_siblings(Net& net)
         a->sib = b;
         b->sib_of = a;
     }
+    // a pair that a new shape un-planned keeps no stacked copy of its filters (the layers' own packed weights stay -- they are what
+    // the pair falls back to, and what Extract-driven level changes run)
+    for (size_t i = 0; i < L; ++i)
+        if (conv[i] && !conv[i]->sib && conv[i]->sib_packed.bytes)
+        {
+            conv[i]->sib_packed.release();
+            conv[i]->sib_bias.release();
+            conv[i]->sib_packed_for = nullptr;
+        }
     return 0;
 }
 

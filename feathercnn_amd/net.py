@@ -145,12 +145,17 @@ class Net:
 
     def chains(self, raw=False):
         """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3).
-        raw=True keeps the library's values: 2 marks the pair "first layer computed inside the next layer's input transform"."""
+        raw=True keeps the library's values: 2 marks the pair "first layer computed inside the next layer's input transform" -- (0, 2) on the
+        first layer, which is not a Winograd layer and launches nothing, (2, x) on its consumer.  The boolean view (raw=False) is about chained
+        Winograd layers only: the first layer is left out of it and the consumer's V is not "from the previous layer's chained transform"."""
         out = {}
         for i in range(self._lib.fhip_net_layer_count(self._h)):
             a, b = ctypes.c_int(), ctypes.c_int()
             if self._lib.fhip_net_layer_chain(self._h, i, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value or b.value):
-                out[i] = (a.value, b.value) if raw else (bool(a.value), bool(b.value))
+                if raw:
+                    out[i] = (a.value, b.value)
+                elif a.value == 1 or b.value == 1:
+                    out[i] = (a.value == 1, b.value == 1)
         return out
 
     def forward_timed(self):

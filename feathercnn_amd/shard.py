@@ -80,15 +80,43 @@ def parse_cpulist(text: str):
     return cpus
 
 
-def rank_cpus(node_cpus, ranks_on_node: int, index_on_node: int, allowed=None):
-    """The contiguous share of a NUMA node's cores that the `index_on_node`-th of `ranks_on_node` ranks gets; restricted to `allowed`
-    (the cores the process may run on) and never empty while `allowed` leaves the node any core."""
+def core_of(cpu: int):
+    """Physical-core key of a logical CPU: the lowest thread sibling (topology/thread_siblings_list), or the CPU itself when the
+    platform does not say (then every logical CPU counts as a core of its own)."""
+    try:
+        return min(parse_cpulist(open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read()))
+    except (OSError, ValueError):
+        return cpu
+
+
+def rank_cpus(node_cpus, ranks_on_node: int, index_on_node: int, allowed=None, core_key=core_of):
+    """The share of a NUMA node's cores that the `index_on_node`-th of `ranks_on_node` ranks gets, split by PHYSICAL core: Linux usually
+    numbers SMT siblings as a second range ('0-31,128-159'), so a split of the sorted cpulist would hand one rank the physical cores and
+    another their hyperthread siblings -- the same cores.  A rank gets whole cores (every allowed sibling of each); restricted to `allowed`
+    (the CPUs the process may run on) and never empty while `allowed` leaves the node any CPU."""
     cpus = sorted(c for c in node_cpus if allowed is None or c in allowed)
     if not cpus or ranks_on_node < 1 or not (0 <= index_on_node < ranks_on_node):
         return []
-    per = max(1, len(cpus) // ranks_on_node)
-    lo = min(index_on_node * per, len(cpus) - per)
-    return cpus[lo:lo + per]
+    cores = {}
+    for c in cpus:
+        cores.setdefault(core_key(c), []).append(c)
+    keys = sorted(cores)
+    per = max(1, len(keys) // ranks_on_node)
+    lo = min(index_on_node * per, len(keys) - per)
+    return sorted(c for k in keys[lo:lo + per] for c in cores[k])
+
+
+def format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11' (inverse of parse_cpulist)."""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
 
 
 def gpu_numa_node(pci_bus_id: str):
@@ -118,6 +146,6 @@ def pin_rank_to_gpu_numa_node(local_rank: int, local_world: int, pci_bus_ids):
             how = f"no NUMA information: share {local_rank + 1}/{local_world} of the allowed cores"
         if cpus:
             os.sched_setaffinity(0, cpus)
-        return {"pinned": bool(cpus), "cpus": f"{cpus[0]}-{cpus[-1]}" if cpus else "", "count": len(cpus), "how": how}
+        return {"pinned": bool(cpus), "cpus": format_cpulist(cpus), "count": len(cpus), "how": how}
     except Exception as e:  # affinity is an optimisation
         return {"pinned": False, "error": repr(e)}

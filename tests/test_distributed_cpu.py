@@ -84,10 +84,19 @@ def test_rank_affinity_shares_numa_cores_between_local_ranks():
     contiguous, disjoint between the ranks of a node, inside the allowed set, and never empty."""
     from feathercnn_amd.shard import parse_cpulist, pin_rank_to_gpu_numa_node, rank_cpus
     assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    from feathercnn_amd.shard import format_cpulist
     node0 = parse_cpulist("0-63,128-191")
-    shares = [rank_cpus(node0, 4, k) for k in range(4)]
+    flat = lambda c: c                       # every logical CPU a core of its own
+    smt = lambda c: c % 128                  # the usual Linux numbering: CPU c and c + 128 are the two threads of core c
+    shares = [rank_cpus(node0, 4, k, core_key=flat) for k in range(4)]
     assert all(len(s) == 32 for s in shares) and len(set().union(*map(set, shares))) == 128
-    assert rank_cpus(node0, 4, 1, allowed=set(range(8))) == [2, 3]          # a restricted cpuset is respected
+    # SMT siblings stay with their core (ADVICE r03): no rank gets only the hyperthreads of a peer's cores
+    shares = [rank_cpus(node0, 4, k, core_key=smt) for k in range(4)]
+    assert all(len(s) == 32 for s in shares) and len(set().union(*map(set, shares))) == 128
+    assert all({c % 128 for c in s if c < 128} == {c % 128 for c in s if c >= 128} for s in shares)
+    assert shares[1] == list(range(16, 32)) + list(range(144, 160)) and format_cpulist(shares[1]) == "16-31,144-159"
+    assert format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11" and format_cpulist([]) == ""
+    assert rank_cpus(node0, 4, 1, allowed=set(range(8)), core_key=flat) == [2, 3]          # a restricted cpuset is respected
     assert rank_cpus([5], 3, 2) == [5] and rank_cpus([], 2, 0) == [] and rank_cpus(node0, 2, 2) == []
     import os
     before = os.sched_getaffinity(0)

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 CMD="python $REPO/bench.py --no-cpu-baseline --no-steady $*"
 echo "== kernel trace + stats: $CMD"
-timeout ${PROF_TIMEOUT:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout ${PROF_TIMEOUT:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD --manifest-out $OUT/manifest.json > $OUT/trace.log 2>&1
 tail -2 $OUT/trace.log
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | tr ' ' '+' | cut -c1-40)

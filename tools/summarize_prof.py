@@ -80,6 +80,14 @@ def main(d):
             w = agg[k]["WRITE_SIZE"][0] / max(agg[k]["WRITE_SIZE"][1], 1)
             dig[k] = {"launches_profiled": agg[k]["FETCH_SIZE"][1], "fetch_kib_raw": f, "write_kib_raw": w,
                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    # which tree / configuration these counters describe (bench.py --manifest-out, written by the kernel-trace pass of tools/profile.sh):
+    # bench.attach_traffic attaches the digest only to a run of the same sources at the same batch and fusion level
+    try:
+        dig["_meta"] = json.load(open(os.path.join(d, "manifest.json")))
+    except (OSError, ValueError):
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from feathercnn_amd import provenance
+        dig["_meta"] = provenance.tree_head()
     with open(os.path.join(d, "traffic.json"), "w") as fo:
         json.dump(dig, fo, indent=1)
 

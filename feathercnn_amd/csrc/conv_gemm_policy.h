@@ -12,6 +12,7 @@ namespace fhip
 {
 
 constexpr int kConvKTile = 16;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4))); // a float4 that is only 4-byte aligned (MODE 5)
 
 struct ConvGemmParams
 {
@@ -50,6 +51,9 @@ struct ConvGemmParams
     // row tile, so a block writes one of the two tensors only.
     float* out2;
     int twin_rows, relu2;
+    // MODE 5 (1x1 / stride 1 on planes whose size is not a multiple of 4 -- ResNet-50's 7 x 7 stage): Ntot counts pixel SLOTS, rag_gpi = ceil(OHW / 4)
+    // groups of 4 per image; group g of an image covers pixels min(4 g, OHW - 4) ... + 3 (the last group is shifted back inside the image)
+    int rag_gpi;
 };
 
 constexpr int kDwFusedMaxC = 256; // channels whose taps the fused route keeps in LDS (12 floats each)
@@ -57,6 +61,12 @@ constexpr int kDwFusedMaxC = 256; // channels whose taps the fused route keeps i
 // MODE 0: generic gather (any kernel / stride / pad)
 // MODE 1: 1x1, pad 0, any stride (no tap decode, no bounds checks)
 // MODE 2: 1x1, stride 1, pad 0, OH*OW % 4 == 0 : the column matrix IS the input -> 16-byte loads
+// MODE 5: 1x1, stride 1, pad 0, OH*OW % 4 != 0 (and >= 4) -- ResNet-50's 7 x 7 stage (round 4).  MODE 1 serves such planes with four scalar
+//         loads per B float4 and four scalar stores (+ four scalar residual loads) per accumulator float4.  Here the GEMM's columns are pixel
+//         SLOTS: every image gets ceil(OHW / 4) groups of 4, the last group is SHIFTED BACK to the image's last four pixels (so every access
+//         stays inside the tensor) -- one unaligned 16-byte load per B float4, one unaligned 16-byte store / residual load per accumulator
+//         float4; the shifted group recomputes up to three pixels of its neighbour and stores only its new ones.  6 % more columns at 7 x 7
+//         (52 slots for 49 pixels), a quarter of the memory instructions.  Same values as MODE 1 bit for bit (same k order per output).
 // MODE 3 / 4: 1x1 stride 1 on the OUTPUT of a 3x3 depthwise convolution (MODE 3: depthwise stride 1, MODE 4: stride 2; pad_left =
 //         pad_top = 1, W % 4 == 0, OW % 4 == 0, C <= kDwFusedMaxC) that is never written: the B loader fetches the depthwise INPUT
 //         patch of its 4 output pixels -- per channel 3 rows x (4-byte, 16-byte, 4- or 16-byte) loads -- and `finish` does the 36
@@ -68,11 +78,12 @@ template <int MODE, bool TWIN = false>
 struct ConvGemmPolicy
 {
     using Params = ConvGemmParams;
-    static constexpr int EXTRA_LDS_FLOATS = MODE >= 3 ? kDwFusedMaxC * 12 : 0;
+    static constexpr bool DW = MODE == 3 || MODE == 4; // depthwise 3x3 computed into the B tile
+    static constexpr int EXTRA_LDS_FLOATS = DW ? kDwFusedMaxC * 12 : 0;
     // MODE 3 / 4: the depthwise taps (9) + bias (slot 9) of every channel -> LDS, once per block
     static __device__ void stage_extra(const Params& p, float* extra, int tid, int threads)
     {
-        if (MODE < 3) return;
+        if (!DW) return;
         for (int i = tid; i < p.C * 12; i += threads)
         {
             const int c = i / 12, e = i - c * 12;
@@ -124,7 +135,7 @@ struct ConvGemmPolicy
         {
             valid = 0;
             koff = k_first(p, split) * kConvKTile;
-            if (MODE >= 3)
+            if (DW)
             {
                 // 4 consecutive columns are 4 consecutive pixels of one output row (OW % 4 == 0, n4 % 4 == 0)
                 const int cc = n4 < p.Ntot ? n4 : 0;
@@ -141,6 +152,14 @@ struct ConvGemmPolicy
                 const int img = n4 / p.OHW, rem = n4 - img * p.OHW;
                 valid = n4 < p.Ntot ? 0xfu : 0u;
                 ptr[0] = p.in + ((size_t)img * p.C) * p.HW + rem;
+            }
+            else if (MODE == 5)
+            {
+                // pixel slots: group (n4 / 4) % gpi of image n4 / (4 gpi), shifted back inside the image if it is the last one
+                const int cc = n4 < p.Ntot ? n4 : 0;
+                const int spi = 4 * p.rag_gpi, img = cc / spi, g4 = cc - img * spi;
+                valid = n4 < p.Ntot ? 0xfu : 0u;
+                ptr[0] = p.in + ((size_t)img * p.C) * p.HW + min(g4, p.OHW - 4);
             }
             else
             {
@@ -167,7 +186,7 @@ struct ConvGemmPolicy
         // MODE 3 / 4: act(dw3x3 + bias) of the 4 pixels, taps accumulated in (m, n) order like depthwise3x3_direct_kernel
         __device__ float4 finish(const Params& p, const Raw& raw, int krow_in_split, const float* extra) const
         {
-            if constexpr (MODE < 3)
+            if constexpr (!DW)
                 return raw;
             else
             {
@@ -221,7 +240,7 @@ struct ConvGemmPolicy
         }
         __device__ Raw load(const Params& p, int krow_in_split, unsigned& ok) const
         {
-            if constexpr (MODE >= 3)
+            if constexpr (DW)
             {
                 const int krow = krow_in_split + koff;
                 ok = krow < p.Kd ? valid : 0u;
@@ -257,6 +276,12 @@ struct ConvGemmPolicy
                 ok = kin ? valid : 0u;
                 return *reinterpret_cast<const float4*>((valid ? ptr[0] : p.in) + (size_t)kr * p.HW);
             }
+            if (MODE == 5)
+            {
+                ok = kin ? valid : 0u;
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(ptr[0] + (size_t)kr * p.HW); // 4-byte aligned: one global_load_dwordx4
+                return make_float4(v.x, v.y, v.z, v.w);
+            }
             float v[4];
             if (MODE == 1)
             {
@@ -291,10 +316,25 @@ struct ConvGemmPolicy
         bool wide; // the 4 columns are one aligned 16-byte piece of one image
         float* part; // split-K: &partial[split][0][n4]
         float* ptr2[TWIN ? 4 : 1]; // TWIN: &out2[img][0][rem] - twin_rows * OHW, so that row m of the GEMM is ptr2[e] + m * OHW
+        int first_new;             // MODE 5: first component of this slot group that no other group covers (0 but for an image's last group)
         __device__ Store(const Params& p, int split, int n4)
         {
             part = p.split_k > 1 ? p.partial + (size_t)split * p.K * p.Ntot + n4 : nullptr;
             valid = 0;
+            first_new = 0;
+            if (MODE == 5)
+            {
+                const int cc = n4 < p.Ntot ? n4 : 0;
+                const int spi = 4 * p.rag_gpi, img = cc / spi, g4 = cc - img * spi, off = min(g4, p.OHW - 4);
+                valid = n4 < p.Ntot ? 0xfu : 0u;
+                first_new = g4 - off;
+                ptr[0] = p.out + ((size_t)img * p.K) * p.OHW + off;
+                ptr[1] = ptr[0] + 1;
+                ptr[2] = ptr[0] + 2;
+                ptr[3] = ptr[0] + 3;
+                wide = false;
+                return;
+            }
             const int k_first = TWIN ? p.twin_rows : p.K; // channels of the tensor `out` points to
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -317,6 +357,15 @@ struct ConvGemmPolicy
         // read element by element in put4b
         __device__ float4 residual4(const Params& p, int m) const
         {
+            if (MODE == 5)
+            {
+                if (p.has_residual && valid && !part && m < p.K)
+                {
+                    const f32x4u r = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(ptr[0] + (size_t)m * p.OHW) + p.residual_delta);
+                    return make_float4(r.x, r.y, r.z, r.w);
+                }
+                return make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             if (p.has_residual && wide && !part && m < p.K)
                 return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr[0] + (size_t)m * p.OHW) + p.residual_delta);
             return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -343,6 +392,41 @@ struct ConvGemmPolicy
             v.z += b;
             v.w += b;
             const size_t moff = (size_t)m * p.OHW;
+            if (MODE == 5)
+            {
+                if (!valid) return;
+                if (p.has_residual)
+                {
+                    v.x += r.x;
+                    v.y += r.y;
+                    v.z += r.z;
+                    v.w += r.w;
+                }
+                if (p.relu)
+                {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                if (first_new == 0)
+                {
+                    f32x4u o;
+                    o.x = v.x;
+                    o.y = v.y;
+                    o.z = v.z;
+                    o.w = v.w;
+                    *reinterpret_cast<f32x4u*>(ptr[0] + moff) = o; // 4-byte aligned: one global_store_dwordx4
+                }
+                else
+                {
+                    // an image's last group: components below first_new are pixels the group before already owns
+                    if (first_new <= 1) ptr[0][moff + 1] = v.y;
+                    if (first_new <= 2) ptr[0][moff + 2] = v.z;
+                    ptr[0][moff + 3] = v.w;
+                }
+                return;
+            }
             if (TWIN)
             {
                 // no residual, no split-K in this form (igemm_twin_forward)

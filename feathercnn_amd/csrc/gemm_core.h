@@ -237,22 +237,36 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     for (int j = 0; j < Shape::TN; ++j)
     {
         const typename Policy::Store st(prm, batch, n0 + wn * Shape::WTN + j * 32 + e_c4);
+        // The fused residual operand (zeros when the layer has none) is requested one 32-row tile AHEAD: tile i + 1's four float4 go out
+        // right after tile i's accumulators went to the transpose scratch -- into the registers those accumulators just left, so the
+        // request costs no occupancy (requesting every tile up front did: 86 -> 104 VGPRs, 5 -> 4 waves per SIMD) -- and their round trip
+        // runs under tile i's LDS reads and stores instead of starting only behind them: one exposed HBM / L2 latency per wave and column
+        // piece instead of TM (round 4; round 3 had already moved the four requests of a tile in front of its transpose).
+        float4 res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) res[q] = st.residual4(prm, m0 + wm * Shape::WTM + e_row + q * 8);
 #pragma unroll
         for (int i = 0; i < Shape::TM; ++i)
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * Shape::EPI_LD + l31] = acc[i][j][r];
             const int mbase = m0 + wm * Shape::WTM + i * 32 + e_row;
-            // the fused residual operand of the four stores below is requested here, so its round trips overlap each other and the LDS
-            // transpose instead of sitting one by one in front of every store (zeros when the layer has none)
-            float4 res[4];
+            float4 nxt[4];
+            if (i + 1 < Shape::TM)
+            {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) res[q] = st.residual4(prm, mbase + q * 8);
+                for (int q = 0; q < 4; ++q) nxt[q] = st.residual4(prm, mbase + 32 + q * 8);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
             {
                 const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * Shape::EPI_LD + e_c4]);
                 st.put4b(prm, mbase + q * 8, v, bias_r[i][q], res[q]);
+            }
+            if (i + 1 < Shape::TM)
+            {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[q] = nxt[q];
             }
         }
     }

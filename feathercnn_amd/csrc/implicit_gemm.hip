@@ -71,6 +71,22 @@ static int ip_pieces(const fhip_conv_param& p)
 }
 static size_t ip_xq_floats(const fhip_conv_param& p) { return round_up_sz((size_t)ip_kq(p) * 256, 64); }
 
+// ---- 1x1 / stride-1 / unpadded layers on planes whose size is not a multiple of 4 (ResNet-50's 7 x 7 stage): ConvGemmPolicy<5> works on pixel
+// SLOTS -- ceil(Ho*Wo / 4) groups of 4 per image, the last one shifted back inside the image -- so the GEMM has batch * 4 * ceil(Ho*Wo / 4)
+// columns instead of batch * Ho*Wo (conv_gemm_policy.h).  Pure functions of geometry and batch: GetBufferSize, the split-K decision and Forward agree.
+static bool ragged_1x1(const fhip_conv_param& p, int batch)
+{
+    const int ohw = p.output_h * p.output_w;
+    return p.group == 1 && p.kernel_h == 1 && p.kernel_w == 1 && p.stride_h <= 1 && p.stride_w <= 1 && p.pad_left == 0 && p.pad_right == 0 &&
+           p.pad_top == 0 && p.pad_bottom == 0 && p.output_h == p.input_h && p.output_w == p.input_w && (ohw % 4) != 0 && ohw >= 4 &&
+           !conv_narrow_n((long long)batch * ohw);
+}
+static long long igemm_columns(const fhip_conv_param& p, int batch)
+{
+    const long long ohw = (long long)p.output_h * p.output_w;
+    return ragged_1x1(p, batch) ? (long long)batch * 4 * ((ohw + 3) / 4) : (long long)batch * ohw;
+}
+
 void igemm_packed_dims(const fhip_conv_param& p, int* kd_padded, int* k_padded);
 size_t igemm_packed_floats(const fhip_conv_param& p)
 {
@@ -97,8 +113,8 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     if (ip_profitable(p, batch)) return 1;     // the streamed InnerProduct has its own pieces (ip_pieces)
     int kdp, kp;
     igemm_packed_dims(p, &kdp, &kp);
-    const long long ntot = (long long)batch * p.output_h * p.output_w;
-    const bool narrow = conv_narrow_n(ntot);
+    const long long ntot = igemm_columns(p, batch);
+    const bool narrow = conv_narrow_n((long long)batch * p.output_h * p.output_w);
     const int bm = (narrow || conv_small_m(p.output_channels)) ? 64 : 128, bn = narrow ? 32 : (conv_small_m(p.output_channels) ? 128 : 64);
     const long long tiles = (long long)(kp / bm) * ((ntot + bn - 1) / bn);
     const int kt = kdp / kConvKTile;
@@ -124,23 +140,37 @@ size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
         return (ip_xq_floats(p) + (size_t)ip_pieces(p) * p.output_channels * batch) * sizeof(float);
     const int s = igemm_split(p, batch);
     if (s <= 1) return 0;
-    return (size_t)s * p.output_channels * ((size_t)batch * p.output_h * p.output_w) * sizeof(float);
+    return (size_t)s * p.output_channels * (size_t)igemm_columns(p, batch) * sizeof(float);
 }
 
 // finishes a split-K convolution: out[img][m][rem] = act(sum_s partial[s][m][n] + bias[m])
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                                  const float* __restrict__ bias, const float* __restrict__ residual, int K,
-                                                                 int Ntot, int OHW, int S, int has_bias, int relu)
+                                                                 int Ntot, int OHW, int S, int has_bias, int relu, int rag_gpi)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
     if (n >= Ntot) return;
+    int img, rem;
+    if (rag_gpi)
+    {
+        // columns are pixel slots (ConvGemmPolicy<5>): slot e of group g4 / 4 is pixel min(g4, OHW - 4) + e; the components of an image's last
+        // group that the group before already owns are dropped
+        const int spi = 4 * rag_gpi, sl = n - (n / spi) * spi, g4 = sl & ~3, e = sl & 3, off = min(g4, OHW - 4);
+        if (e < g4 - off) return;
+        img = n / spi;
+        rem = off + e;
+    }
+    else
+    {
+        img = n / OHW;
+        rem = n - img * OHW;
+    }
     const size_t stride = (size_t)K * Ntot;
     const float* src = partial + (size_t)m * Ntot + n;
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += src[(size_t)s * stride];
     if (has_bias) v += bias[m];
-    const int img = n / OHW, rem = n - img * OHW;
     const size_t o = ((size_t)img * K + m) * OHW + rem;
     if (residual) v += residual[o];
     if (relu) v = fmaxf(v, 0.f);
@@ -512,6 +542,7 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     const long long ntot = (long long)batch * g.OHW;
     if (ntot > 0x7fffff00LL) return fail(FHIP_E_BADARG, "N*Ho*Wo exceeds 32-bit column indices");
     g.Ntot = (int)ntot;
+    g.rag_gpi = 0;
     g.has_bias = p.bias_term != 0;
     g.relu = (p.activation == FHIP_ACT_RELU) && !force_no_act;
     if (!residual && smallc_applicable(p))
@@ -586,6 +617,15 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     const bool one = g.KH == 1 && g.KW == 1 && p.pad_left == 0 && p.pad_right == 0 && p.pad_top == 0 && p.pad_bottom == 0;
     int mode = 0;
     if (one) mode = (g.SH == 1 && g.SW == 1 && (g.OHW % 4) == 0) ? 2 : 1;
+    if (ragged_1x1(p, batch))
+    {
+        // planes that are not a multiple of 4 pixels: the columns become pixel slots (ConvGemmPolicy<5>)
+        mode = 5;
+        g.rag_gpi = (g.OHW + 3) / 4;
+        const long long slots = igemm_columns(p, batch);
+        if (slots > 0x7fffff00LL) return fail(FHIP_E_BADARG, "N*Ho*Wo exceeds 32-bit column indices");
+        g.Ntot = (int)slots;
+    }
     const bool small = conv_small_m(g.K);
     StageTimer tm(FHIP_STAGE_IGEMM, s);
     if (conv_narrow_n(ntot))
@@ -596,13 +636,15 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     }
     else if (small)
     {
-        if (mode == 2) launch<ConvShapeSmallM, 2>(g, s);
+        if (mode == 5) launch<ConvShapeSmallM, 5>(g, s);
+        else if (mode == 2) launch<ConvShapeSmallM, 2>(g, s);
         else if (mode == 1) launch<ConvShapeSmallM, 1>(g, s);
         else launch<ConvShapeSmallM, 0>(g, s);
     }
     else
     {
-        if (mode == 2) launch<ConvShapeBig, 2>(g, s);
+        if (mode == 5) launch<ConvShapeBig, 5>(g, s);
+        else if (mode == 2) launch<ConvShapeBig, 2>(g, s);
         else if (mode == 1) launch<ConvShapeBig, 1>(g, s);
         else launch<ConvShapeBig, 0>(g, s);
     }
@@ -610,7 +652,7 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     if (g.split_k > 1)
     {
         hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot, 256), g.K), dim3(256), 0, s, out, g.partial, bias, residual, g.K,
-                           g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu);
+                           g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu, g.rag_gpi);
         FHIP_CHECK_HIP(hipGetLastError());
     }
     return FHIP_OK;
@@ -691,6 +733,7 @@ int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int b
     g.m_tiles = 0;
     g.dw_w12 = g.dw_bias = nullptr;
     g.dw_stride = g.dw_relu = 0;
+    g.rag_gpi = 0;
     StageTimer tm(FHIP_STAGE_IGEMM, s);
     if (g.SH == 1 && g.SW == 1 && (g.OHW % 4) == 0) launch<ConvShapeBig, 2, true>(g, s);
     else launch<ConvShapeBig, 1, true>(g, s);
@@ -736,6 +779,7 @@ int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch
     g.in = in;
     g.out = out;
     g.out2 = nullptr;
+    g.rag_gpi = 0;
     g.twin_rows = g.relu2 = 0;
     g.bias = pw_bias;
     g.C = pw.input_channels;

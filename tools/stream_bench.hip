@@ -13,6 +13,7 @@
 
 #include "feather_hip/feather_hip.h"
 #include "stream_gemm_exp.h"
+#include "stream_split.h"
 
 using namespace fhip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -144,6 +145,19 @@ static void run(const Case& cs)
     if (cs.C >= 32) vars.push_back({"persistent D8 2048", [&] { launch_persistent<8>(q, 2048); }});
     if (cs.C >= 64) vars.push_back({"persistent D16 3072", [&] { launch_persistent<16>(q, 3072); }});
     if (cs.C >= 32) vars.push_back({"persistent D8 6144", [&] { launch_persistent<8>(q, 6144); }});
+    if (getenv("STREAM_SPLITN"))
+    {
+        // round 4: S-way split of the reduction over the waves of a block, any S (stream_split.h); waves = tiles * S
+        vars.resize(3); // product, stream D8, stream D16
+        const int Q = cs.C / 2 / 8, mgs = q.mgroups;
+#define SPLITN(S_, G_) if (Q >= S_ && mgs % G_ == 0) vars.push_back({"split S" #S_ " x" #G_ " D8", [&] { launch_splitn<8, S_, G_>(q); }})
+        SPLITN(2, 1); SPLITN(3, 1); SPLITN(4, 1); SPLITN(5, 1); SPLITN(6, 1); SPLITN(7, 1); SPLITN(8, 1);
+        SPLITN(2, 2); SPLITN(3, 2); SPLITN(4, 2); SPLITN(2, 4);
+#undef SPLITN
+        printf("   wave tiles %d (x S waves on 1024 SIMDs: S=1 %.2f, 2 %.2f, 3 %.2f, 4 %.2f, 5 %.2f, 6 %.2f, 7 %.2f, 8 %.2f)\n", q.px_tiles * mgs, q.px_tiles * mgs / 1024.0,
+               q.px_tiles * mgs * 2 / 1024.0, q.px_tiles * mgs * 3 / 1024.0, q.px_tiles * mgs * 4 / 1024.0, q.px_tiles * mgs * 5 / 1024.0, q.px_tiles * mgs * 6 / 1024.0,
+               q.px_tiles * mgs * 7 / 1024.0, q.px_tiles * mgs * 8 / 1024.0);
+    }
     std::vector<std::vector<double>> ms(vars.size());
     for (int round = 0; round < 3; ++round)
         for (size_t v = 0; v < vars.size(); ++v)

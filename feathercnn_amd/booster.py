@@ -243,6 +243,18 @@ def winograd_plan(param: ConvParam):
     return pl
 
 
+def winograd_rows(buf, plan, rows: int):
+    """A Winograd scratch tensor (V: rows = input channels, M: rows = output channels) as [64 xi][rows][Pp], whatever its storage: the
+    library keeps V and M in blocks of plan.column_block columns, [Pp / BP][64][rows][BP] (include/feather_hip/feather_hip.h; BP == Pp is
+    the whole-row form).  Works on torch tensors and numpy arrays (flat, at least 64 * rows * Pp floats)."""
+    pp, bp = plan.columns_padded, plan.column_block
+    flat = buf.reshape(-1)[:64 * rows * pp]
+    if bp >= pp:
+        return flat.reshape(64, rows, pp)
+    blocked = flat.reshape(pp // bp, 64, rows, bp)
+    return (blocked.permute(1, 2, 0, 3) if hasattr(blocked, "permute") else blocked.transpose(1, 2, 0, 3)).reshape(64, rows, pp)
+
+
 def can_chain_winograd(a: "ConvLayer", b: "ConvLayer", pool: bool = False) -> bool:
     ca, cb = a.param._c(), b.param._c()
     return bool(_lib.load_library().fhip_conv_can_chain_winograd(ctypes.byref(ca), a.booster.algo, ctypes.byref(cb), b.booster.algo, int(pool)))

@@ -13,6 +13,7 @@
 #pragma once
 
 #include "common.h"
+#include "wino_layout.h"
 
 namespace fhip
 {
@@ -32,6 +33,7 @@ struct WinoFirstParams
     int relu;
     int N, bpi;        // staged form: images, blocks per image (64 tiles each)
     int LDW, rows;     // staged form: LDS row pitch 6 TX + 4 and the most patch rows a block stages
+    WinoLayout Lv;     // where the consumer's V (rows = K) lives
 };
 
 constexpr unsigned kWinoFirstOob = 0x40000000u; // + any in-range offset (and + itself) is still >= num_records
@@ -138,12 +140,14 @@ __global__ __launch_bounds__(256, 4) void wino_input_from_first_kernel(const Win
     for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
 
     // uniform base (scalar registers, advanced on the scalar unit) + one 32-bit lane offset: no 64-bit vector adds per store
-    const size_t xi_stride = (size_t)q.K * q.Pp;
-    const unsigned lane_off = (unsigned)k * (unsigned)q.Pp + (unsigned)p;
+    // uniform per-xi base (scalar registers) + one lane offset: no 64-bit vector adds per store
+    const size_t xi_stride = q.Lv.xis;
+    float* const vb = q.V + (size_t)k * q.Lv.bp;
+    const size_t lane_off = q.Lv.col(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) (q.V + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
+        for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
 }
 
 
@@ -211,7 +215,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
     const int ty = t / q.TX, tx = t - ty * q.TX;
     const int y0 = 6 * ty - 1, x0 = 6 * tx - 1;
     const float* patch = smem + (size_t)(6 * (ty - ty0)) * q.LDW + 6 * tx; // image (6 ty - 2, 6 tx - 2)
-    const size_t xi_stride = (size_t)q.K * q.Pp;
+    const size_t xi_stride = q.Lv.xis;
+    // the lane's column: its block, relative to the block of the wave's first column (a wave's 64 columns touch at most two blocks), so the
+    // per-store address stays a wave-uniform base + one 32-bit lane offset
+    const int p_lane = n * q.T + t, p_first = __builtin_amdgcn_readfirstlane(n * q.T + t0);
+    const size_t col_first = q.Lv.col(p_first);
+    const unsigned lane_off = (unsigned)(q.Lv.col(p_lane) - col_first);
     const float lo = q.relu ? 0.f : -__builtin_huge_valf();
     // activation + the consumer's zero padding in two instructions per value: clamp(a, lo_i, hi_i) with [lo_i, hi_i] = [lo, inf) on rows of the
     // window inside the image and [0, 0] outside, then a select on the column (64 precomputed (row, column) lane masks would not fit the
@@ -291,11 +300,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
 #pragma unroll
         for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
         // wave-uniform base (scalar registers) + the lane's tile index: no 64-bit vector address arithmetic per store
-        float* vb = q.V + (size_t)k * q.Pp + (size_t)n * q.T + t0;
+        float* vb = q.V + (size_t)k * q.Lv.bp + col_first;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane] = d[i][j];
+            for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
     }
 }
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
     const float* srcA = prm.U + (size_t)xi * prm.Cp * prm.Kp + (size_t)(wave * RPW + half) * prm.Kp + m0 + l31 * 4;
     // B: wave w covers rows RPW*w .. RPW*w + RPW-1 (16 lanes x 16 B per row, 4 rows per piece)
     const int brow = wave * RPW + (lane >> 4);
-    const float* srcB = prm.V + (size_t)xi * prm.C * prm.Pp + n0 + (lane & 15) * 4;
+    const float* srcB = prm.V + (size_t)xi * prm.Lv.xis + prm.Lv.col(n0) + (lane & 15) * 4; // the 64-column tile lies inside one column block
     const size_t a_step = (size_t)BK * prm.Kp;
 
     auto issue = [&](int kt, int buf) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
         for (int i = 0; i < RPW / 4; ++i)
         {
             const int r = min(kt * BK + brow + 4 * i, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp, (lds_void*)(base + BK * BM + (wave * RPW + 4 * i) * BN), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp, (lds_void*)(base + BK * BM + (wave * RPW + 4 * i) * BN), 16, 0, 0);
         }
     };
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
     // epilogue (gemm_core.h): per-wave LDS transpose, 16-byte row stores
     float* const scr = lds + wave * (32 * EPI_LD);
     const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
-    float* mbase = prm.M + (size_t)xi * prm.K * prm.Pp + n0 + wn * 32 + e_c4;
+    float* mbase = prm.M + (size_t)xi * prm.Lm.xis + prm.Lm.col(n0) + wn * 32 + e_c4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
     {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
         {
             const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * EPI_LD + e_c4]);
             const int m = mrow + q * 8;
-            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Pp) = v;
+            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
         }
     }
 }
@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
     const float* srcA = prm.U + (size_t)xi * prm.Cp * prm.Kp + (size_t)(wave * 4 + half) * prm.Kp + m0 + l31 * 4;
     const size_t a_step = (size_t)BK * prm.Kp;
     // B: piece j = wave (and wave + 4 for waves 0, 1) is float4 elements 64 j .. 64 j + 63 of the [16][24 float4] tile
-    const float* srcB = prm.V + (size_t)xi * prm.C * prm.Pp + n0;
+    // (a 96-column tile may straddle column blocks of V / M: every 16-byte piece is addressed through the layout; whole rows otherwise)
+    const float* srcB = prm.V + (size_t)xi * prm.Lv.xis;
     const int e0 = wave * 64 + lane, e1 = (wave + 4) * 64 + lane;
-    const int b0_row = e0 / 24, b0_col = (e0 - b0_row * 24) * 4, b1_row = e1 / 24, b1_col = (e1 - b1_row * 24) * 4;
+    const int b0_row = e0 / 24, b1_row = e1 / 24;
+    const size_t b0_col = prm.Lv.col(n0 + (e0 - b0_row * 24) * 4), b1_col = prm.Lv.col(n0 + (e1 - b1_row * 24) * 4);
 
     auto issue = [&](int kt, int buf) {
         float* base = lds + buf * BUF_FLOATS;
@@ -166,12 +168,12 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
         float* bb = base + BK * BM;
         {
             const int r = min(kt * BK + b0_row, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp + b0_col, (lds_void*)(bb + wave * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b0_col, (lds_void*)(bb + wave * 256), 16, 0, 0);
         }
         if (wave < 2)
         {
             const int r = min(kt * BK + b1_row, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Pp + b1_col, (lds_void*)(bb + (wave + 4) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b1_col, (lds_void*)(bb + (wave + 4) * 256), 16, 0, 0);
         }
     };
 
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
 #pragma unroll
     for (int j = 0; j < 3; ++j)
     {
-        float* mbase = prm.M + (size_t)xi * prm.K * prm.Pp + n0 + j * 32 + e_c4;
+        float* mbase = prm.M + (size_t)xi * prm.Lm.xis + prm.Lm.col(n0 + j * 32 + e_c4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[j][r];
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
         {
             const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * EPI_LD + e_c4]);
             const int m = mrow + q * 8;
-            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Pp) = v;
+            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
         }
     }
 }

@@ -105,6 +105,7 @@ struct WinoXformParams
     int TX, T;   // tiles per row, tiles per image
     int P, Pp;   // columns, padded columns
     int N;
+    WinoLayout Lv, Lm; // where V (rows = C) and M (rows = K) live (wino_layout.h)
 };
 
 __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __restrict__ V, const float* __restrict__ in,
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __rest
 #pragma unroll
     for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
 
-    const size_t xi_stride = (size_t)q.C * q.Pp;
-    float* vp = V + (size_t)c * q.Pp + p;
+    const size_t xi_stride = q.Lv.xis;
+    float* vp = V + (size_t)c * q.Lv.bp + q.Lv.col(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(float* __res
     const int n = p / q.T, t = p - n * q.T;
     const int ty = t / q.TX, tx = t - ty * q.TX;
 
-    const size_t xi_stride = (size_t)q.K * q.Pp;
-    const float* mp = M + (size_t)k * q.Pp + p;
+    const size_t xi_stride = q.Lm.xis;
+    const float* mp = M + (size_t)k * q.Lm.bp + q.Lm.col(p);
     float m[8][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
     if (active)
     {
         const int p = (u0 + unit_l) * q.TX + tx;
-        const size_t xi_stride = (size_t)q.K * q.Pp;
-        const float* mp = M + (size_t)k * q.Pp + p;
+        const size_t xi_stride = q.Lm.xis;
+        const float* mp = M + (size_t)k * q.Lm.bp + q.Lm.col(p);
         float m[8][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -376,6 +377,7 @@ struct WinoChain
                       // consecutive columns of M and V' (a 14 x 14 plane alone is 9 columns = 36 bytes of a row)
     int ppb;          // planes per block
     int LDW, LDH;     // LDS plane: (AH + 2 rows) x LDW floats, 2 border columns left, >= 2 right
+    WinoLayout Lm, Lv2; // layer L's M (rows = K) and the consumer's V' (rows = K): wino_layout.h
 };
 
 // (the pooled form fits 96 registers: 5 waves per SIMD let a third 6-wave block of the 112 -> 56 px boundary on a CU, 116.6 -> 114.2 us)
@@ -411,14 +413,14 @@ __global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __
     }
 
     // ---- phase 1: layer L's tiles -> activation plane(s) in LDS
-    const size_t xi_stride = (size_t)g.K * g.Pp;
+    const size_t xi_stride = g.Lm.xis;
     for (int w = tid; w < np * g.T; w += nthreads)
     {
         const int pl = w / g.T, t = w - pl * g.T;
         const int plane = plane0 + pl;
         const int k = plane / g.N, n = plane - k * g.N;
         const int ty = t / g.TX, tx = t - ty * g.TX;
-        const float* mp = M + (size_t)k * g.Pp + (size_t)n * g.T + t;
+        const float* mp = M + (size_t)k * g.Lm.bp + g.Lm.col(n * g.T + t);
         float m[8][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __
 
     // ---- phase 2: the consumer's tiles: window rows 6ty-1 .. 6ty+6, columns 6tx-1 .. 6tx+6 of the activation = LDS rows 6ty .. 6ty+7,
     // columns 6tx+1 .. 6tx+8 (one border row on top, two border columns on the left)
-    const size_t xi_stride2 = (size_t)g.K * g.Pp2;
+    const size_t xi_stride2 = g.Lv2.xis;
     for (int w = tid; w < np * g.T2; w += nthreads)
     {
         const int pl = w / g.T2, t = w - pl * g.T2;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __
         for (int j = 0; j < 8; ++j) bt8(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
-        float* vp = Vn + (size_t)k * g.Pp2 + (size_t)n * g.T2 + t;
+        float* vp = Vn + (size_t)k * g.Lv2.bp + g.Lv2.col(n * g.T2 + t);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -516,6 +518,19 @@ constexpr int kWinoKTile = 16;    // reduction padding of U
 
 static bool wino_small_m(int K) { return K <= 64; }
 
+// Column block BP of a layer's V and M (wino_layout.h): a pure function of the geometry, like everything else GetBufferSize, the stage-level
+// entry points and Forward must agree on.  0 = whole rows.  FHIP_WINO_BP (build-time, tools/layout_ab.sh) overrides the rule for A/B runs.
+// Measured (round 4, VGG-16 b32 and ResNet-50 b64 in the net, tools/layout_ab.sh + tools/layout_trace.sh: every layer on BP = 0 / 256 / 512 /
+// 1024 / 2048 / 4096): only the HBM-bound tile GEMM of the 64 -> 64-channel layers gains -- VGG-16's conv1_2 321.7 -> 300.8 us at BP = 512,
+// 291.0 at 1024 (tools/gemm_bench.hip GEMM_LAYOUT=1 in isolation: 396 -> 378 / 328 / 319 us at BP = 128 / 256 / 512) -- while the MFMA-bound
+// GEMMs do not move (+-1 %), conv2_1's (64 -> 128) gets 1 - 3 % slower and the chained transforms 0 - 7 % slower at BP <= 512.  So: blocks of
+// 1024 columns for layers with at most 64 output channels (the 64 x 128 GEMM tile), whole rows everywhere else.
+#ifdef FHIP_WINO_BP
+static int wino_col_block(const fhip_conv_param&, int columns) { return columns > FHIP_WINO_BP ? FHIP_WINO_BP : 0; }
+#else
+static int wino_col_block(const fhip_conv_param& p, int columns) { return (wino_small_m(p.output_channels) && columns > 1024) ? 1024 : 0; }
+#endif
+
 int winograd_plan(const fhip_conv_param& p, int batch, fhip_winograd_plan* plan)
 {
     if (p.kernel_h != 3 || p.kernel_w != 3 || p.stride_h > 1 || p.stride_w > 1 || p.group > 1)
@@ -530,7 +545,9 @@ int winograd_plan(const fhip_conv_param& p, int batch, fhip_winograd_plan* plan)
     const long long P = (long long)plan->tiles_per_image * batch;
     if (P > 0x7fffff00LL) return fail(FHIP_E_BADARG, "too many Winograd tiles for 32-bit column indices");
     plan->columns = (int)P;
-    plan->columns_padded = round_up((int)P, kWinoColTile);
+    plan->column_block = wino_col_block(p, (int)P);
+    plan->columns_padded = round_up((int)P, std::max(kWinoColTile, plan->column_block));
+    if (plan->column_block <= 0 || plan->column_block >= plan->columns_padded) plan->column_block = plan->columns_padded; // whole rows
     plan->in_channels_padded = round_up(p.input_channels, kWinoKTile);
     plan->out_channels_padded = round_up(p.output_channels, wino_small_m(p.output_channels) ? 64 : 128);
     plan->v_offset_bytes = 0;
@@ -557,6 +574,8 @@ static WinoXformParams xform_params(const fhip_conv_param& p, int batch, const f
     q.P = pl.columns;
     q.Pp = pl.columns_padded;
     q.N = batch;
+    q.Lv = wino_layout(q.C, q.Pp, pl.column_block);
+    q.Lm = wino_layout(q.K, q.Pp, pl.column_block);
     return q;
 }
 
@@ -627,6 +646,7 @@ int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_para
     q.T = pl.tiles_per_image;
     q.P = pl.columns;
     q.Pp = pl.columns_padded;
+    q.Lv = wino_layout(q.K, q.Pp, pl.column_block);
     q.in_bytes = (unsigned)(4ull * batch * first.input_channels * first.input_h * first.input_w);
     q.relu = first.activation == FHIP_ACT_RELU;
     StageTimer tm(FHIP_STAGE_WINO_INPUT, s);
@@ -677,6 +697,8 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     g.Cp = pl.in_channels_padded;
     g.Kp = pl.out_channels_padded;
     g.Pp = pl.columns_padded;
+    g.Lv = wino_layout(g.C, g.Pp, pl.column_block);
+    g.Lm = wino_layout(g.K, g.Pp, pl.column_block);
     g.k_tiles = g.Cp / kWinoKTile;
     StageTimer tm(FHIP_STAGE_WINO_GEMM, s);
     if (wino_small_m(g.K))
@@ -807,6 +829,8 @@ int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_para
     g.TX2 = pn.tiles_x;
     g.T2 = pn.tiles_per_image;
     g.Pp2 = pn.columns_padded;
+    g.Lm = wino_layout(g.K, g.Pp, pl.column_block);
+    g.Lv2 = wino_layout(g.K, g.Pp2, pn.column_block);
     const long long planes = (long long)batch * g.K;
     if (planes > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N*K too large");
     g.planes = (int)planes;

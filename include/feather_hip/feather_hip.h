@@ -125,11 +125,12 @@ typedef struct fhip_winograd_plan
     int tiles_x, tiles_y;   /* nRowBlocks, nColBlocks (avx/booster.cpp:209-210)          */
     int tiles_per_image;    /* T                                                        */
     int columns;            /* P = T * batch                                            */
-    int columns_padded;     /* P rounded up to the GEMM column tile                     */
+    int columns_padded;     /* Pp: P rounded up to the GEMM column tile and to column_block */
+    int column_block;       /* BP: V and M are stored in blocks of BP columns, [Pp / BP][64][rows][BP]; BP == Pp: whole rows */
     int in_channels_padded; /* C rounded up to the GEMM reduction tile (U only)         */
     int out_channels_padded;/* K rounded up to the GEMM row tile (U only)               */
-    size_t v_offset_bytes, v_bytes; /* V[64][C][Pp]                                     */
-    size_t m_offset_bytes, m_bytes; /* M[64][K][Pp]                                     */
+    size_t v_offset_bytes, v_bytes; /* V[Pp / BP][64][C][BP]                            */
+    size_t m_offset_bytes, m_bytes; /* M[Pp / BP][64][K][BP]                            */
     size_t u_bytes;                 /* U[64][Cp][Kp] = processed kernel                 */
 } fhip_winograd_plan;
 

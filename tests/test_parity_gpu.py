@@ -177,7 +177,8 @@ _AT = np.array([[1, 1, 1, 1, 1, 32, 32, 0], [0, 1, -1, 2, -2, 16, -16, 0], [0, 1
                 [0, 1, 1, 16, 16, 2, 2, 0], [0, 1, -1, 32, -32, 1, -1, 1]], np.float64)
 
 
-def test_winograd_stage_api(cuda):
+@pytest.mark.parametrize("n", [3, 90])  # 36 columns (whole rows of V / M) and 1080 (column blocks of 1024, the second one mostly padding)
+def test_winograd_stage_api(cuda, n):
     import ctypes
 
     import torch
@@ -185,7 +186,6 @@ def test_winograd_stage_api(cuda):
     from feathercnn_amd import ConvParam, _lib, booster
     lib = _lib.load_library()
     g = conv_geom(12, 20, 17, 3, 1, 1, w=23)
-    n = 3
     x, w, b = synth(g, n, seed=5)
     p = ConvParam.make(g.ic, g.oc, g.ih, 3, 1, 1, w=g.iw, batch=n)
     pl = booster.winograd_plan(p)
@@ -214,10 +214,11 @@ def test_winograd_stage_api(cuda):
     xp[:, :, 1:1 + g.ih, 1:1 + g.iw] = x
     patches = np.stack([xp[:, :, 6 * ty:6 * ty + 8, 6 * tx:6 * tx + 8] for ty in range(pl.tiles_y) for tx in range(TX)], axis=2)
     Vref = np.einsum("ia,nctab,jb->ijcnt", _BT, patches, _BT).reshape(64, g.ic, P)
-    assert nerr(V.cpu().numpy()[:, :, :P], Vref) <= 1e-5
+    # (V and M are stored in column blocks -- fhip_winograd_plan.column_block; winograd_rows gives the [64][rows][Pp] view)
+    assert nerr(booster.winograd_rows(V, pl, g.ic).cpu().numpy()[:, :, :P], Vref) <= 1e-5
     # M = U V per frequency point
     Mref = np.einsum("xck,xcp->xkp", Uref, Vref)
-    assert nerr(M.cpu().numpy()[:, :, :P], Mref) <= 1e-5
+    assert nerr(booster.winograd_rows(M, pl, g.oc).cpu().numpy()[:, :, :P], Mref) <= 1e-5
     # Y = A^T M A + bias, ReLU, clipped
     Y = np.einsum("ai,ijknt,bj->nktab", _AT, Mref.reshape(8, 8, g.oc, n, T), _AT)
     full = np.zeros((n, g.oc, 6 * pl.tiles_y, 6 * TX))

@@ -3,6 +3,7 @@
 //   usage: gemm_bench [reps]
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include <cmath>
 #include <algorithm>
@@ -11,6 +12,7 @@
 #include "gemm_core_probe.h"
 #include "wino_gemm_policy.h"
 #include "wino_gemm_glds.h"
+#include "wino_gemm_c64.h"
 
 using namespace fhip;
 namespace fhip
@@ -40,6 +42,8 @@ struct Case
 static int g_cus = 256;
 static int g_batches = 64;
 static int g_ref_pp = 0;
+static int g_bp = 0; // column block of V / M (GEMM_BP)
+static int g_c64_blocks = 2; // persistent blocks per CU of wino_gemm_c64_kernel
 static long long* g_prof = nullptr;
 
 template <class Shape, int ABLATE, int V0 = 0>
@@ -63,6 +67,11 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
         g.n_tiles = (cs.P + 95) / 96;
         g.Pp = std::max(g.Pp, g.n_tiles * 96);
     }
+    // round 4: column-blocked V / M (wino_layout.h); GEMM_BP = 0 / unset: whole rows
+    const int bp = g_bp && g_bp % Shape::BN == 0 && V0 != 7 ? g_bp : 0;
+    if (bp) g.Pp = round_up(g.Pp, bp);
+    g.Lv = wino_layout(g.C, g.Pp, bp);
+    g.Lm = wino_layout(g.K, g.Pp, bp);
     const int tiles = g.batches * g.m_tiles * g.n_tiles;
     dim3 grid(tiles);
     auto launch = [&]() {
@@ -76,6 +85,8 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 3>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 7)
             hipLaunchKernelGGL(wino_gemm_glds96_kernel, grid, dim3(256), 0, 0, g);
+        else if constexpr (V0 == 8)
+            hipLaunchKernelGGL(wino_gemm_c64_kernel, dim3(std::min(tiles, g_cus * g_c64_blocks)), dim3(256), 0, 0, g); // persistent
         else
             hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, WinoGemmPolicy, ABLATE>), grid, dim3(Shape::THREADS), 0, 0, g);
     };
@@ -104,14 +115,14 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
             got[w].resize(plane);
             CK(hipMemcpy(got[w].data(), M + (size_t)(w ? g_batches - 1 : 0) * plane, plane * 4, hipMemcpyDeviceToHost));
         }
-        if (fresh && ABLATE == 0 && V0 == 0)
+        if (fresh && ABLATE == 0 && V0 == 0 && !bp)
         {
             ref[0] = got[0];
             ref[1] = got[1];
             ref_case = cs;
             g_ref_pp = g.Pp;
         }
-        else if (!fresh && ABLATE == 0 && g.Pp == g_ref_pp)
+        else if (!fresh && ABLATE == 0 && g.Pp == g_ref_pp && !bp)
         {
             double worst = 0, scale = 0;
             for (int w = 0; w < 2; ++w)
@@ -135,7 +146,7 @@ int main(int argc, char** argv)
     // the Winograd tile-GEMM shapes of VGG-16 at batch 32 (C, K, P)
     // (GEMM_RESNET: ResNet-50's 3x3 layers at batch 64 instead)
     const Case vgg[] = {{64, 64, 46208}, {64, 128, 11552}, {128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}};
-    const Case resnet[] = {{128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {256, 256, 576}, {512, 512, 256}};
+    const Case resnet[] = {{64, 64, 6400}, {256, 256, 576}, {512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {256, 256, 576}, {512, 512, 256}};
     const Case* cases_p = getenv("GEMM_RESNET") ? resnet : vgg;
     Case cases[8];
     for (int i = 0; i < 8; ++i) cases[i] = cases_p[i];
@@ -143,8 +154,8 @@ int main(int argc, char** argv)
     for (auto& c : cases)
     {
         maxU = std::max(maxU, (size_t)64 * round_up(c.C, 32) * round_up(c.K, 256));
-        maxV = std::max(maxV, (size_t)64 * c.C * round_up(c.P, 384));
-        maxM = std::max(maxM, (size_t)64 * c.K * round_up(c.P, 384));
+        maxV = std::max(maxV, (size_t)64 * c.C * round_up(c.P, 1536));
+        maxM = std::max(maxM, (size_t)64 * c.K * round_up(c.P, 1536));
     }
     float *U, *V, *M;
     CK(hipMalloc(&U, maxU * 4));
@@ -185,6 +196,49 @@ int main(int argc, char** argv)
                 run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>("128x64 glds (product)", c, U, V, M, reps);
                 run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 7>("128x96 glds", c, U, V, M, reps);
             }
+            continue;
+        }
+        if (getenv("GEMM_C64"))
+        {
+            // round 4: the persistent streaming kernel for C, K <= 64 against the product's one-tile-per-block kernel, whole rows and column blocks
+            if (c.C > 64 || c.K > 64) continue;
+            for (int round = 0; round < 3; ++round)
+                for (int bp : {0, 1024})
+                {
+                    g_bp = bp;
+                    char nm[64];
+                    snprintf(nm, sizeof nm, "64x128 reg-staged (product) BP %d", bp);
+                    run<GemmShape<64, 128, 16, 1, 4, 4>, 0>(nm, c, U, V, M, reps);
+                    for (int bpc : {1, 2})
+                    {
+                        g_c64_blocks = bpc;
+                        snprintf(nm, sizeof nm, "c64 persistent %d/CU BP %d", bpc, bp);
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 8>(nm, c, U, V, M, reps);
+                    }
+                }
+            g_bp = 0;
+            continue;
+        }
+        if (getenv("GEMM_LAYOUT"))
+        {
+            // whole rows against column blocks of 64 ... 512, the product's kernel for the shape, interleaved rounds
+            for (int round = 0; round < 3; ++round)
+                for (int bp : {0, 64, 128, 256, 512})
+                {
+                    g_bp = bp;
+                    char nm[64];
+                    snprintf(nm, sizeof nm, "BP %d", bp);
+                    if (c.K <= 64)
+                    {
+                        if (bp == 64) continue;
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0>((std::string("64x128 reg-staged ") + nm).c_str(), c, U, V, M, reps);
+                    }
+                    else if (c.C < 128)
+                        run<GemmShape<128, 64, 16, 2, 2, 4>, 0>((std::string("128x64 reg-staged ") + nm).c_str(), c, U, V, M, reps);
+                    else
+                        run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3>((std::string("128x64 glds ") + nm).c_str(), c, U, V, M, reps);
+                }
+            g_bp = 0;
             continue;
         }
         for (int round = 0; round < 3; ++round)

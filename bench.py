@@ -358,17 +358,25 @@ def attribute(net, reps):
                 row.update({"fused_pointwise_K": q.output_channels, "pair_gbs": round(4.0 * (p.input_channels * p.input_h * p.input_w + q.output_channels *
                             q.output_h * q.output_w) * n / max(ms, 1e-9) / 1e6, 1), "pair_mfma_frac": round(pfl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)})
             elif a_id == WINOGRADF63:
-                tiles = ((p.output_h + 5) // 6) * ((p.output_w + 5) // 6)
-                gemm_flops += 2.0 * 64 * p.output_channels * p.input_channels * tiles * n
+                # tiles and frequency points as the library runs the layer (fhip_winograd_f63_plan): 64 points on 6 x 6-output tiles, or -- planes
+                # of 7 / 8 output pixels per side, round 4 -- 36 points on 4 x 4-output tiles; the work counted is the work executed
+                import ctypes
+                from feathercnn_amd import _lib
+                pl_ = _lib.fhip_winograd_plan()
+                if _lib.load_library().fhip_winograd_f63_plan(ctypes.byref(p), n, ctypes.byref(pl_)) != 0:
+                    raise SystemExit("bench: fhip_winograd_f63_plan failed on a layer the net runs as Winograd")
+                tiles, nxi = pl_.tiles_per_image, pl_.frequency_points
+                gemm_flops += 2.0 * nxi * p.output_channels * p.input_channels * tiles * n
+                row["winograd"] = f"F({pl_.tile_outputs}x{pl_.tile_outputs},3x3), {nxi} frequency points, {tiles} tiles per image"
                 v_in, v_out = chains.get(i, (0, 0))
                 if not v_in:
-                    k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + 64 * p.input_channels * tiles) * n
+                    k2_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + nxi * p.input_channels * tiles) * n
                 elif v_in == 2:
-                    first_bytes += 4.0 * 64 * p.input_channels * tiles * n  # V written by the fused first-layer + input transform
+                    first_bytes += 4.0 * nxi * p.input_channels * tiles * n  # V written by the fused first-layer + input transform
                 else:
-                    chain_bytes += 4.0 * 64 * p.input_channels * tiles * n   # V' written by the chained transform of the layer before
+                    chain_bytes += 4.0 * nxi * p.input_channels * tiles * n   # V' written by the chained transform of the layer before
                 if v_out:
-                    chain_bytes += 4.0 * 64 * p.output_channels * tiles * n  # M read by this layer's chained transform
+                    chain_bytes += 4.0 * nxi * p.output_channels * tiles * n  # M read by this layer's chained transform
                     row["chained_to_next"] = True
             elif a_id == DEPTHWISE:
                 dw_bytes += 4.0 * (p.input_channels * p.input_h * p.input_w + p.output_channels * p.output_h * p.output_w) * n + 40.0 * p.input_channels
@@ -403,7 +411,7 @@ def attribute(net, reps):
     roofs = []
     if gemm_flops and stage.get("wino_gemm"):
         roofs.append(roofline_mfma("Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", gemm_flops,
-                                   stage["wino_gemm"], "algorithmic FLOPs 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N summed over the Winograd layers of a step / "
+                                   stage["wino_gemm"], "algorithmic FLOPs 2*xi*K*C*T*N (xi = 64 frequency points, T = ceil(Ho/6)*ceil(Wo/6) tiles; 7- and 8-pixel planes: xi = 36, T = ceil(Ho/4)*ceil(Wo/4)) summed over the Winograd layers of a step / "
                                    "sum of their tile-GEMM HIP-event durations on the launch stream"))
     if pw_flops and pw_ms:
         r = roofline_mfma("1x1 implicit GEMM: gemm_mfma_kernel<ConvGemmPolicy<1|2>> (+ split-K reduce) / stream_gemm_kernel (C >= 256, 128 <= K <= 512)", pw_flops, pw_ms,

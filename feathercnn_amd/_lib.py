@@ -19,7 +19,8 @@ class fhip_conv_param(ctypes.Structure):
 
 class fhip_winograd_plan(ctypes.Structure):
     _fields_ = [("tiles_x", ctypes.c_int), ("tiles_y", ctypes.c_int), ("tiles_per_image", ctypes.c_int),
-                ("columns", ctypes.c_int), ("columns_padded", ctypes.c_int), ("column_block", ctypes.c_int), ("in_channels_padded", ctypes.c_int),
+                ("columns", ctypes.c_int), ("columns_padded", ctypes.c_int), ("column_block", ctypes.c_int), ("frequency_points", ctypes.c_int), ("tile_outputs", ctypes.c_int),
+                ("in_channels_padded", ctypes.c_int),
                 ("out_channels_padded", ctypes.c_int), ("v_offset_bytes", ctypes.c_size_t), ("v_bytes", ctypes.c_size_t),
                 ("m_offset_bytes", ctypes.c_size_t), ("m_bytes", ctypes.c_size_t), ("u_bytes", ctypes.c_size_t)]
 

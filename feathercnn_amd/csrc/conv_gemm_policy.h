@@ -188,6 +188,10 @@ struct ConvGemmPolicy
         {
             if constexpr (!DW)
                 return raw;
+#ifdef FHIP_DWPW_ABLATE // measurement builds only (tools/dwpw_ab.sh): bit 0 = no depthwise arithmetic
+            else if constexpr ((FHIP_DWPW_ABLATE & 1) != 0)
+                return raw.c[1];
+#endif
             else
             {
                 const int c = min(krow_in_split + koff, p.C - 1);
@@ -254,6 +258,24 @@ struct ConvGemmPolicy
                 {
                     const int y = min(max(iy0[0] + m, 0), p.H - 1); // padding rows re-read a real row and are skipped in finish
                     const float* row = plane + (size_t)y * p.W;
+#ifdef FHIP_DWPW_ABLATE // bit 1 = no halo loads (3 aligned float4 per channel instead of 9 mixed loads), bit 2 = the centre row only
+                    if ((FHIP_DWPW_ABLATE & 4) && m != 1)
+                    {
+                        raw.l[m] = 0.f;
+                        raw.c[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (MODE == 3) raw.r[m] = 0.f;
+                        else raw.r[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        continue;
+                    }
+                    if (FHIP_DWPW_ABLATE & 2)
+                    {
+                        raw.l[m] = 0.f;
+                        raw.c[m] = *reinterpret_cast<const float4*>(row + x0);
+                        if constexpr (MODE == 3) raw.r[m] = 0.f;
+                        else raw.r[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        continue;
+                    }
+#endif
                     raw.l[m] = row[xl];
                     raw.c[m] = *reinterpret_cast<const float4*>(row + x0);
                     if constexpr (MODE == 3)

@@ -21,14 +21,14 @@ struct WinoLayout
     int shift;     // log2(BP); 31 for the whole-row form (p >> 31 == 0 for every column)
     unsigned mask; // BP - 1; 0x7fffffff for the whole-row form
     int bp;        // row pitch: BP (whole rows: Pp)
-    size_t blk;    // floats per column block = 64 * rows * BP (whole rows: unused, 0)
+    size_t blk;    // floats per column block = (frequency points) * rows * BP (whole rows: unused, 0)
     size_t xis;    // floats from xi to xi + 1 inside a block = rows * bp
     // offset of column p in row 0 of xi 0
     __host__ __device__ __forceinline__ size_t col(int p) const { return (size_t)((unsigned)p >> shift) * blk + ((unsigned)p & mask); }
 };
 
-// BP >= Pp (or 0) -> whole rows
-inline WinoLayout wino_layout(int rows, int Pp, int BP)
+// BP >= Pp (or 0) -> whole rows; nxi = frequency points of the transform (64 for F(6,3), 36 for F(4,3))
+inline WinoLayout wino_layout(int rows, int Pp, int BP, int nxi = 64)
 {
     WinoLayout L;
     if (BP <= 0 || BP >= Pp)
@@ -45,7 +45,7 @@ inline WinoLayout wino_layout(int rows, int Pp, int BP)
         L.shift = s;
         L.mask = (unsigned)BP - 1u;
         L.bp = BP;
-        L.blk = (size_t)64 * rows * BP;
+        L.blk = (size_t)nxi * rows * BP;
     }
     L.xis = (size_t)rows * L.bp;
     return L;

@@ -510,6 +510,144 @@ __global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// F(4x4, 3x3) for planes of 7 or 8 output pixels per side (round 4; ResNet-50's res5 3x3 layers).  The reference sends such layers to
+// IM2COL (avx/booster.cpp:289: h, w <= 8); this library's tuned rule runs them as Winograd, and on a 7 x 7 plane F(6x6,3x3) needs 2 x 2 tiles
+// of 6 x 6 outputs -- 144 computed for 49 used -- with 64 frequency points each.  2 x 2 tiles of 4 x 4 outputs cover 8 x 8 with 36 frequency
+// points: 0.5625 x the tile-GEMM work and 0.5625 x the V / M bytes for the same layer.  Same pipeline (filter transform -> input transform ->
+// 36 GEMMs through the same kernels -> output transform), same layouts with 36 in place of 64; Lavin's matrices
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// (smaller constants than F(6,3): the results are closer to the fp64 convolution than the F(6,3) route's).
+__device__ __forceinline__ void bt6(float& r0, float& r1, float& r2, float& r3, float& r4, float& r5)
+{
+    const float o0 = (4.f * r0 - 5.f * r2) + r4;
+    const float o5 = (4.f * r1 - 5.f * r3) + r5;
+    const float a = r4 - 4.f * r2, b = r3 - 4.f * r1; // rows 1, 2: a +- b
+    const float c = r4 - r2, e = 2.f * (r3 - r1);     // rows 3, 4: c +- e
+    r0 = o0;
+    r1 = a + b;
+    r2 = a - b;
+    r3 = c + e;
+    r4 = c - e;
+    r5 = o5;
+}
+
+__device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float& s0, float& s1, float& s2, float& s3)
+{
+    const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
+    s0 = (m0 + a12) + a34;
+    s1 = d12 + 2.f * d34;
+    s2 = a12 + 4.f * a34;
+    s3 = (d12 + 8.f * d34) + m5;
+}
+
+__global__ __launch_bounds__(256) void wino43_filter_transform_kernel(float* __restrict__ U, const float* __restrict__ w, int C, int K, int Cp, int Kp)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= K) return;
+    const float* g = w + ((size_t)k * C + c) * 9;
+    float gg[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gg[i][j] = g[i * 3 + j];
+    const float G[6][3] = {{0.25f, 0.0f, 0.0f},           {-1.0f / 6, -1.0f / 6, -1.0f / 6}, {-1.0f / 6, 1.0f / 6, -1.0f / 6},
+                           {1.0f / 24, 1.0f / 12, 1.0f / 6}, {1.0f / 24, -1.0f / 12, 1.0f / 6},   {0.0f, 0.0f, 1.0f}};
+    float mid[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mid[i][j] = G[i][0] * gg[0][j] + G[i][1] * gg[1][j] + G[i][2] * gg[2][j];
+    const size_t xi_stride = (size_t)Cp * Kp;
+    float* up = U + (size_t)c * Kp + k;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) up[(size_t)(i * 6 + j) * xi_stride] = mid[i][0] * G[j][0] + mid[i][1] * G[j][1] + mid[i][2] * G[j][2];
+}
+
+// V = B^T d B on 6x6 tiles at stride 4, one tile per lane (lanes along the column index p, as in K2)
+__global__ __launch_bounds__(256) void wino43_input_transform_kernel(float* __restrict__ V, const float* __restrict__ in, const WinoXformParams q)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)q.C * q.P) return;
+    const int c = (int)(idx / q.P);
+    const int p = (int)(idx - (long long)c * q.P);
+    const int n = p / q.T, t = p - n * q.T;
+    const int ty = t / q.TX, tx = t - ty * q.TX;
+    const int y0 = ty * 4 - q.PT, x0 = tx * 4 - q.PL;
+    const float* ip = in + ((size_t)n * q.C + c) * q.H * q.W;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+    {
+        const int y = y0 + i;
+        const bool yok = (unsigned)y < (unsigned)q.H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+        {
+            const int x = x0 + j;
+            const bool ok = yok && ((unsigned)x < (unsigned)q.W);
+            d[i][j] = ok ? ip[(size_t)y * q.W + x] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    const size_t xi_stride = q.Lv.xis;
+    float* vp = V + (size_t)c * q.Lv.bp + q.Lv.col(p);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) vp[(size_t)(i * 6 + j) * xi_stride] = d[i][j];
+}
+
+// Y = A^T m A, + bias, ReLU, clipped 4x4 store.  Planes of at most 8 x 8: a (image, channel) plane is the 2 x 2 tiles of four consecutive lanes.
+template <bool HAS_BIAS, bool RELU>
+__global__ __launch_bounds__(256) void wino43_output_transform_kernel(float* __restrict__ out, const float* __restrict__ M, const float* __restrict__ bias,
+                                                                     const WinoXformParams q)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (p >= q.P) return;
+    const int n = p / q.T, t = p - n * q.T;
+    const int ty = t / q.TX, tx = t - ty * q.TX;
+    const size_t xi_stride = q.Lm.xis;
+    const float* mp = M + (size_t)k * q.Lm.bp + q.Lm.col(p);
+    float m[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = mp[(size_t)(i * 6 + j) * xi_stride];
+    float tmp[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) at4(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j]);
+    const float b = HAS_BIAS ? bias[k] : 0.f;
+    const int oy0 = ty * 4, ox0 = tx * 4;
+    float* op = out + (((size_t)n * q.K + k) * q.OH + oy0) * q.OW + ox0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+    {
+        float y[4];
+        at4(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], y[0], y[1], y[2], y[3]);
+        if (oy0 + a < q.OH)
+        {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                if (ox0 + bb < q.OW)
+                {
+                    float v = y[bb] + b;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    op[(size_t)a * q.OW + bb] = v;
+                }
+        }
+    }
+}
+
 // K3: the tile GEMM is gemm_core.h driven by WinoGemmPolicy (wino_gemm_policy.h)
 using WinoShapeBig = GemmShape<128, 64, 16, 2, 2>;     // K > 64: measured best on C >= 256 (73 % vs 70 %) and on small P
 using WinoShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
@@ -517,6 +655,18 @@ constexpr int kWinoColTile = 128; // column padding of V / M
 constexpr int kWinoKTile = 16;    // reduction padding of U
 
 static bool wino_small_m(int K) { return K <= 64; }
+
+// F(4x4,3x3) instead of F(6x6,3x3): planes of at most 8 output pixels per side on which 4 x 4 output tiles need fewer (tile, frequency point)
+// pairs than 6 x 6 ones -- 7 and 8 pixels per side (2 x 2 x 36 = 144 against 2 x 2 x 64 = 256); 5- and 6-pixel planes are ONE F(6,3) tile.
+// A pure function of the geometry (GetBufferSize, Init, Forward and the stage-level entry points agree); the chained / pooled / first-layer
+// forms are F(6,3)-only and refuse such layers.
+static bool wino_f43(const fhip_conv_param& p)
+{
+    if (p.kernel_h != 3 || p.kernel_w != 3 || p.stride_h > 1 || p.stride_w > 1 || p.group > 1) return false;
+    const int oh = p.input_h + p.pad_top + p.pad_bottom - 2, ow = p.input_w + p.pad_left + p.pad_right - 2; // = AssignOutputDim's
+    if (oh < 1 || ow < 1 || oh > 8 || ow > 8 || (oh < 7 && ow < 7)) return false; // planes up to 6 x 6 are ONE F(6,3) tile and keep their chains
+    return ((oh + 3) / 4) * ((ow + 3) / 4) * 36 < ((oh + 5) / 6) * ((ow + 5) / 6) * 64;
+}
 
 // Column block BP of a layer's V and M (wino_layout.h): a pure function of the geometry, like everything else GetBufferSize, the stage-level
 // entry points and Forward must agree on.  0 = whole rows.  FHIP_WINO_BP (build-time, tools/layout_ab.sh) overrides the rule for A/B runs.
@@ -541,6 +691,17 @@ int winograd_plan(const fhip_conv_param& p, int batch, fhip_winograd_plan* plan)
     // nRowBlocks / nColBlocks exactly as WINOGRADF63_Forward (avx/booster.cpp:209-211)
     plan->tiles_x = (wp + 3) / 6;
     plan->tiles_y = (hp + 3) / 6;
+    plan->frequency_points = 64;
+    plan->tile_outputs = 6;
+    if (wino_f43(p))
+    {
+        // 7- and 8-pixel planes: 2 x 2 tiles of F(4x4,3x3) (36 frequency points) instead of 2 x 2 tiles of F(6x6,3x3) (64)
+        plan->tiles_x = (wp + 1) / 4;
+        plan->tiles_y = (hp + 1) / 4;
+        plan->frequency_points = 36;
+        plan->tile_outputs = 4;
+    }
+    const int nxi = plan->frequency_points;
     plan->tiles_per_image = plan->tiles_x * plan->tiles_y;
     const long long P = (long long)plan->tiles_per_image * batch;
     if (P > 0x7fffff00LL) return fail(FHIP_E_BADARG, "too many Winograd tiles for 32-bit column indices");
@@ -551,10 +712,10 @@ int winograd_plan(const fhip_conv_param& p, int batch, fhip_winograd_plan* plan)
     plan->in_channels_padded = round_up(p.input_channels, kWinoKTile);
     plan->out_channels_padded = round_up(p.output_channels, wino_small_m(p.output_channels) ? 64 : 128);
     plan->v_offset_bytes = 0;
-    plan->v_bytes = round_up_sz((size_t)64 * p.input_channels * plan->columns_padded * sizeof(float), 256);
+    plan->v_bytes = round_up_sz((size_t)nxi * p.input_channels * plan->columns_padded * sizeof(float), 256);
     plan->m_offset_bytes = plan->v_bytes;
-    plan->m_bytes = round_up_sz((size_t)64 * p.output_channels * plan->columns_padded * sizeof(float), 256);
-    plan->u_bytes = (size_t)64 * plan->in_channels_padded * plan->out_channels_padded * sizeof(float);
+    plan->m_bytes = round_up_sz((size_t)nxi * p.output_channels * plan->columns_padded * sizeof(float), 256);
+    plan->u_bytes = (size_t)nxi * plan->in_channels_padded * plan->out_channels_padded * sizeof(float);
     return FHIP_OK;
 }
 
@@ -574,8 +735,8 @@ static WinoXformParams xform_params(const fhip_conv_param& p, int batch, const f
     q.P = pl.columns;
     q.Pp = pl.columns_padded;
     q.N = batch;
-    q.Lv = wino_layout(q.C, q.Pp, pl.column_block);
-    q.Lm = wino_layout(q.K, q.Pp, pl.column_block);
+    q.Lv = wino_layout(q.C, q.Pp, pl.column_block, pl.frequency_points);
+    q.Lm = wino_layout(q.K, q.Pp, pl.column_block, pl.frequency_points);
     return q;
 }
 
@@ -587,8 +748,12 @@ int winograd_transform_kernel(const fhip_conv_param& p, float* u, const float* k
     StageTimer tm(FHIP_STAGE_INIT, s);
     FHIP_CHECK_HIP(hipMemsetAsync(u, 0, pl.u_bytes, s));
     dim3 grid(ceil_div(p.output_channels, 256), p.input_channels);
-    hipLaunchKernelGGL(wino_filter_transform_kernel, grid, dim3(256), 0, s, u, kernel, p.input_channels, p.output_channels,
-                       pl.in_channels_padded, pl.out_channels_padded);
+    if (pl.frequency_points == 36)
+        hipLaunchKernelGGL(wino43_filter_transform_kernel, grid, dim3(256), 0, s, u, kernel, p.input_channels, p.output_channels, pl.in_channels_padded,
+                           pl.out_channels_padded);
+    else
+        hipLaunchKernelGGL(wino_filter_transform_kernel, grid, dim3(256), 0, s, u, kernel, p.input_channels, p.output_channels,
+                           pl.in_channels_padded, pl.out_channels_padded);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -603,7 +768,10 @@ int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, cons
     const long long work = (long long)q.C * q.P;
     if ((work + 255) / 256 > 0x7fffffffLL) return fail(FHIP_E_BADARG, "input transform grid too large");
     dim3 grid((unsigned)((work + 255) / 256));
-    hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
+    if (pl.frequency_points == 36)
+        hipLaunchKernelGGL(wino43_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
+    else
+        hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
 }
@@ -617,7 +785,7 @@ bool winograd_can_fuse_first(const fhip_conv_param& first, const fhip_conv_param
         return c.kernel_h == 3 && c.kernel_w == 3 && c.stride_h == 1 && c.stride_w == 1 && c.group == 1 && c.pad_left == 1 && c.pad_right == 1 &&
                c.pad_top == 1 && c.pad_bottom == 1;
     };
-    if (!k3p1(first) || !k3p1(next) || batch < 1) return false;
+    if (!k3p1(first) || !k3p1(next) || batch < 1 || wino_f43(next)) return false;
     if (first.input_channels < 2 || first.input_channels > 4 || next.input_channels != first.output_channels) return false;
     if (first.activation != FHIP_ACT_NONE && first.activation != FHIP_ACT_RELU) return false;
     if (next.input_h != first.input_h || next.input_w != first.input_w || (first.input_w & 1)) return false; // float2 image reads: even rows
@@ -688,7 +856,7 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     int rc = winograd_plan(p, batch, &pl);
     if (rc) return rc;
     WinoGemmPolicy::Params g;
-    g.batches = 64;
+    g.batches = pl.frequency_points;
     g.U = u;
     g.V = v;
     g.M = m;
@@ -697,8 +865,8 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     g.Cp = pl.in_channels_padded;
     g.Kp = pl.out_channels_padded;
     g.Pp = pl.columns_padded;
-    g.Lv = wino_layout(g.C, g.Pp, pl.column_block);
-    g.Lm = wino_layout(g.K, g.Pp, pl.column_block);
+    g.Lv = wino_layout(g.C, g.Pp, pl.column_block, pl.frequency_points);
+    g.Lm = wino_layout(g.K, g.Pp, pl.column_block, pl.frequency_points);
     g.k_tiles = g.Cp / kWinoKTile;
     StageTimer tm(FHIP_STAGE_WINO_GEMM, s);
     if (wino_small_m(g.K))
@@ -744,6 +912,7 @@ static void launch_staged(dim3 grid, size_t lds, hipStream_t s, bool has_bias, b
 
 bool winograd_can_pool(const fhip_conv_param& p)
 {
+    if (wino_f43(p)) return false; // the pooled output transform is F(6,3)-only
     return (p.output_h % 2) == 0 && (p.output_w % 2) == 0 && ceil_div(p.output_w, 6) <= 256;
 }
 
@@ -759,6 +928,21 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
     if (has_bias && !bias) return fail(FHIP_E_BADARG, "bias_term set but bias_arr is NULL");
     if (pool && !winograd_can_pool(p)) return fail(FHIP_E_UNSUPPORTED, "fused 2x2 max pooling needs even output dims");
     StageTimer tm(FHIP_STAGE_WINO_OUTPUT, s);
+    if (pl.frequency_points == 36)
+    {
+        if (pool) return fail(FHIP_E_UNSUPPORTED, "fused max pooling is not available on F(4x4,3x3) planes");
+        dim3 grid(ceil_div(q.P, 256), q.K);
+        if (has_bias && relu)
+            hipLaunchKernelGGL((wino43_output_transform_kernel<true, true>), grid, dim3(256), 0, s, output, m, bias, q);
+        else if (has_bias)
+            hipLaunchKernelGGL((wino43_output_transform_kernel<true, false>), grid, dim3(256), 0, s, output, m, bias, q);
+        else if (relu)
+            hipLaunchKernelGGL((wino43_output_transform_kernel<false, true>), grid, dim3(256), 0, s, output, m, bias, q);
+        else
+            hipLaunchKernelGGL((wino43_output_transform_kernel<false, false>), grid, dim3(256), 0, s, output, m, bias, q);
+        FHIP_CHECK_HIP(hipGetLastError());
+        return FHIP_OK;
+    }
     if (q.TX <= 256)
     {
         WinoStaged g;
@@ -798,6 +982,7 @@ bool winograd_can_chain(const fhip_conv_param& p, const fhip_conv_param& next, i
     if (next.kernel_h != 3 || next.kernel_w != 3 || next.stride_h > 1 || next.stride_w > 1 || next.group > 1) return false;
     if (next.pad_left != 1 || next.pad_right != 1 || next.pad_top != 1 || next.pad_bottom != 1) return false;
     if (next.input_channels != p.output_channels) return false;
+    if (wino_f43(p) || wino_f43(next)) return false; // the chained transform is F(6,3) -> F(6,3) only
     if (pool && ((p.output_h & 1) || (p.output_w & 1))) return false;
     const int ah = pool ? p.output_h / 2 : p.output_h, aw = pool ? p.output_w / 2 : p.output_w;
     if (next.input_h != ah || next.input_w != aw) return false;

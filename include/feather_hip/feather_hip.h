@@ -127,6 +127,9 @@ typedef struct fhip_winograd_plan
     int columns;            /* P = T * batch                                            */
     int columns_padded;     /* Pp: P rounded up to the GEMM column tile and to column_block */
     int column_block;       /* BP: V and M are stored in blocks of BP columns, [Pp / BP][64][rows][BP]; BP == Pp: whole rows */
+    int frequency_points;   /* 64: F(6x6,3x3) on 8x8 input tiles; 36: F(4x4,3x3) on 6x6 input tiles -- planes of 7 or 8 output pixels per side,
+                               where 2x2 tiles of 4x4 outputs waste far less than 2x2 tiles of 6x6 (round 4; "64" above then reads 36) */
+    int tile_outputs;       /* 6 or 4: output pixels per tile side                      */
     int in_channels_padded; /* C rounded up to the GEMM reduction tile (U only)         */
     int out_channels_padded;/* K rounded up to the GEMM row tile (U only)               */
     size_t v_offset_bytes, v_bytes; /* V[Pp / BP][64][C][BP]                            */

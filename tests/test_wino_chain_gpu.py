@@ -117,12 +117,12 @@ def _net_outputs(p, b, img, level, blob, graph=False):
 
 
 def test_net_fusion_level_3_chains_vgg_and_equals_level_2(cuda):
-    """VGG-16 at 64 x 64 (same layer structure as the benchmark net): level 3 chains conv1_2 ... conv5_3 and computes conv1_1 inside
-    conv1_2's input transform -- the same logits as level 2 to rounding (bit-identical but for conv1_1's summation order), the blobs in
-    between are gone, the arena holds two V slots + M."""
+    """VGG-16 at 96 x 96 (same layer structure as the benchmark net; planes of 96 / 48 / 24 / 12 / 6 pixels): level 3 chains conv1_2 ...
+    conv5_3 and computes conv1_1 inside conv1_2's input transform -- the same logits as level 2 to rounding (bit-identical but for conv1_1's
+    summation order), the blobs in between are gone, the arena holds two V slots + M."""
     from feathercnn_amd import model_zoo
-    p, b, i, o = model_zoo.vgg16(size=64, classes=10)
-    img = np.random.default_rng(3).uniform(-1, 1, (3, 3, 64, 64)).astype(np.float32)
+    p, b, i, o = model_zoo.vgg16(size=96, classes=10)
+    img = np.random.default_rng(3).uniform(-1, 1, (3, 3, 96, 96)).astype(np.float32)
     net2, out2 = _net_outputs(p, b, img, 2, "fc8")
     net3, out3 = _net_outputs(p, b, img, 3, "fc8", graph=True)
     assert nerr(out3, out2) <= 1e-5
@@ -139,8 +139,23 @@ def test_net_fusion_level_3_chains_vgg_and_equals_level_2(cuda):
     assert not net2.chains()
     with pytest.raises(Exception, match="fusion level 3"):
         net3.Extract("pool2")  # between conv2_2 (+pool) and conv3_1: no storage at level 3
-    assert net2.Extract("pool2").shape == (3, 128, 16, 16)
-    assert net3.Extract("pool5").shape == (3, 512, 2, 2)  # the run's last output exists
+    assert net2.Extract("pool2").shape == (3, 128, 24, 24)
+    assert net3.Extract("pool5").shape == (3, 512, 3, 3)  # the run's last output exists
+
+
+def test_f43_planes_break_a_chain_and_keep_the_result(cuda):
+    """VGG-16 at 64 x 64: conv4_x run on 8 x 8 planes, which take the F(4x4,3x3) form (round 4) -- the chained transform is F(6,3)-only, so
+    the run ends at conv3_3, conv4_1 ... conv4_3 are plain Winograd layers, conv5_x (4 x 4 planes, one F(6,3) tile) chain again; logits equal
+    level 2 to rounding."""
+    from feathercnn_amd import model_zoo
+    p, b, i, o = model_zoo.vgg16(size=64, classes=10)
+    img = np.random.default_rng(3).uniform(-1, 1, (3, 3, 64, 64)).astype(np.float32)
+    net2, out2 = _net_outputs(p, b, img, 2, "fc8")
+    net3, out3 = _net_outputs(p, b, img, 3, "fc8", graph=True)
+    assert nerr(out3, out2) <= 1e-5
+    names = {net3.layers()[k][1]: v for k, v in net3.chains(raw=True).items()}
+    assert names["conv3_3"] == (1, 0) and all(n not in names for n in ("conv4_1", "conv4_2", "conv4_3")), names
+    assert names["conv5_1"] == (0, 1) and names["conv5_3"] == (1, 0), names
 
 
 def test_net_level_3_leaves_branching_and_non_winograd_layers_alone(cuda):

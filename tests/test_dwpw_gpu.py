@@ -16,7 +16,11 @@ TOL = 1e-4
 # and only 64 < K < 160 (stride 1) / 400 (stride 2) is fused: the range where one kernel beats two)
 PAIRS = [(32, 96, 112, 112, 1, 2, 1, 1, 1, 1), (64, 128, 112, 112, 2, 2, 1, 1, 1, 1), (128, 128, 56, 56, 1, 3, 1, 1, 1, 1), (128, 256, 56, 56, 2, 2, 1, 1, 1, 1),
          (256, 144, 28, 28, 1, 24, 1, 1, 1, 1), (16, 72, 16, 16, 1, 3, 0, 1, 0, 1), (8, 200, 24, 16, 2, 2, 1, 0, 1, 0), (12, 100, 10, 16, 1, 2, 0, 0, 0, 0),
-         (20, 65, 9, 8, 1, 5, 1, 1, 1, 1), (40, 72, 6, 16, 2, 3, 1, 1, 0, 1), (128, 390, 12, 24, 2, 2, 1, 1, 1, 1), (3, 130, 20, 24, 1, 1, 1, 1, 1, 1)]
+         (20, 65, 9, 8, 1, 5, 1, 1, 1, 1), (40, 72, 6, 16, 2, 3, 1, 1, 0, 1), (128, 390, 12, 24, 2, 2, 1, 1, 1, 1), (3, 130, 20, 24, 1, 1, 1, 1, 1, 1),
+         # round 4: MobileNet's 112- and 56-pixel pair geometries with image heights that are not the benchmark's, no bias / no activation,
+         # several blocks of output channels
+         (32, 128, 10, 112, 1, 2, 0, 1, 0, 1), (64, 128, 100, 112, 2, 2, 1, 1, 1, 1), (64, 256, 18, 112, 2, 1, 1, 0, 1, 0), (128, 128, 50, 56, 1, 2, 1, 1, 1, 1),
+         (128, 128, 56, 56, 1, 2, 0, 0, 0, 0), (128, 256, 60, 56, 2, 2, 1, 1, 1, 1), (128, 384, 14, 56, 2, 1, 1, 1, 0, 1)]
 
 
 def _layers(cuda, c, k, h, w, s, batch, dw_act, pw_act, dw_bias, pw_bias, seed):

@@ -7,7 +7,7 @@ VARS="${VARS:-0 1 2 3 6 7}"
 if [ "$1" = build ]; then
   for v in $VARS; do
     mkdir -p $R/tools/_build/dwpw_$v
-    make -s -j8 -C $R/feathercnn_amd/csrc OBJDIR=/tmp/fhip_obj_dwpw_$v OUT=$R/tools/_build/dwpw_$v/libfeather_hip.so EXTRA=$([ $v = 0 ] && echo "" || echo "-DFHIP_DWPW_ABLATE=$v")
+    make -s -j8 -C $R/feathercnn_amd/csrc OBJDIR=/tmp/fhip_obj_dwpw_$v OUT=$R/tools/_build/dwpw_$v/libfeather_hip.so EXTRA=$([ $v = 0 ] && echo "" || echo "-D${MACRO:-FHIP_DWPW_ABLATE}=$v")
     echo "built dwpw_$v"
   done
   exit 0

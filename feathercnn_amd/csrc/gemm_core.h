@@ -91,7 +91,7 @@ struct GemmShape
 //   * the lane's bias values are requested in the prologue (Policy::bias_at) instead of one dependent global load in front of
 //          every accumulator store (8 serialised L2 round trips per wave and tile).
 // Measured on ResNet-50 / MobileNet 1x1 layers: +3 ... +7 % on the shallow ones (C <= 128), nothing on the deep ones.  Two other
-// epilogues were measured and dropped (DESIGN.md 3.4): storing straight from the accumulators of an MFMA with swapped operand
+// epilogues were measured and dropped (DESIGN.md 3.9): storing straight from the accumulators of an MFMA with swapped operand
 // roles (32-byte store pieces: -20 %) and batching the LDS transpose of a whole 32-column piece (block latency -3000 cycles,
 // throughput unchanged).
 template <class Shape, class Policy>

@@ -758,7 +758,7 @@ bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int b
     // Worth it?  The fused kernel costs ~1.4x the pointwise GEMM alone (the 36 FMAs per operand vector issue next to the MFMAs), the
     // two-kernel form costs the GEMM plus an HBM-bound depthwise pass of 4*C*(HWin + HWout)*N bytes: with the GEMM at ~60 % of the
     // fp32 MFMA peak and HBM at ~5 TB/s the fused form wins while (HWin / HWout + 1) * 38 / K > 0.45, i.e. K < 160 behind a stride-1
-    // and K < 400 behind a stride-2 depthwise layer.  Measured on MobileNet-V1 b256 (DESIGN.md 3.5): C64->K128 s2 0.374 -> 0.310 ms,
+    // and K < 400 behind a stride-2 depthwise layer.  Measured on MobileNet-V1 b256 (DESIGN.md 3.4): C64->K128 s2 0.374 -> 0.310 ms,
     // C128->K128 s1 0.455 -> 0.369, C128->K256 s2 0.250 -> 0.238; C256->K256 s1 0.358 -> 0.337 and C32->K64 (64-row tile, two operand
     // requests per thread) 0.414 -> 0.404 are inside the noise and stay two kernels.
     if (pw.output_channels <= 64 || pw.output_channels >= (s == 1 ? 160 : 400)) return false;

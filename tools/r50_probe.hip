@@ -17,6 +17,7 @@
 
 #include "conv_gemm_policy.h"
 #include "gemm_core_probe.h"
+#include "gemm_il.h"
 
 using namespace fhip;
 
@@ -108,7 +109,13 @@ static void launch_core(const fhip_conv_param& p, int batch, const float* packed
     g.k_tiles = g.Kdp / 16;
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = (g.Ntot + Shape::BN - 1) / Shape::BN;
-    if (PRODUCT)  // the library's kernel (residual operand requested ahead of the LDS transpose) instead of the instrumented copy (per-store request)
+    if (PRODUCT && Shape::WTM == 32 && Shape::WTN == 128)
+    {
+        // round 4: the transpose-free epilogue (gemm_core.h gemm_mfma_il_kernel)
+        if constexpr (Shape::WTM == 32 && Shape::WTN == 128)
+            hipLaunchKernelGGL((gemm_mfma_il_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
+    }
+    else if (PRODUCT)  // the library's kernel (residual operand requested ahead of the LDS transpose) instead of the instrumented copy (per-store request)
         hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE>>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
     else
         hipLaunchKernelGGL((gemm_mfma_probe_kernel<Shape, ConvGemmPolicy<MODE>, ABL, 3>), dim3(g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, 0, g);
@@ -228,9 +235,34 @@ int main(int argc, char** argv)
             shape("64x64   4 waves 2x2 (32x32 each)", GemmShape<64, 64, 16, 2, 2, 8>(), 64, 64);
             shape("128x32  2 waves 2x1 (64x32 each)", GemmShape<128, 32, 16, 2, 1, 5>(), 128, 32);
             shape("64x256  4 waves 1x4 (64x64 each)", GemmShape<64, 256, 16, 1, 4, 3>(), 64, 256);
+            auto il = [&](const char* nm, auto tag, int bmv, int bnv) {
+                using Sh = decltype(tag);
+                if (bmv > (small ? 64 : 128)) return;
+                vars.push_back({nm, [&, vec] { if (vec) launch_core<Sh, 2, 0, true>(p, cs.N, packed, in, out, bias); else launch_core<Sh, 1, 0, true>(p, cs.N, packed, in, out, bias); }});
+                nblk.push_back((round_up(cs.K, bmv) / bmv) * ceil_div(cs.N * p.output_h * p.output_w, bnv));
+            };
+            il("IL 128x128 4 waves 4x1 (32x128 each)", GemmShape<128, 128, 16, 4, 1, 4>(), 128, 128);
+            il("IL 64x128  2 waves 2x1 (32x128 each)", GemmShape<64, 128, 16, 2, 1, 8>(), 64, 128);
+            il("IL 64x256  4 waves 2x2 (32x128 each)", GemmShape<64, 256, 16, 2, 2, 4>(), 64, 256);
+            il("IL 128x256 8 waves 4x2 (32x128 each)", GemmShape<128, 256, 16, 4, 2, 2>(), 128, 256);
             if (!small) vars.push_back({"128x64  4 waves, loads 2 tiles deep", [&, vec] { if (vec) launch_core<GemmShape<128, 64, 16, 2, 2, 4>, 2, 256>(p, cs.N, packed, in, out, bias); else launch_core<GemmShape<128, 64, 16, 2, 2, 4>, 1, 256>(p, cs.N, packed, in, out, bias); }}), nblk.push_back(0);
             vars.push_back({"product (C-ABI)", [&] { CF(fhip_conv_forward(&p, FHIP_IM2COL, cs.N, out, in, packed, buf, bias, nullptr)); }});
             nblk.push_back(0);
+            {
+                // correctness of every variant against the product's result (bit-identical: same k order per output)
+                std::vector<float> ref(out_n), got(out_n);
+                CF(fhip_conv_forward(&p, FHIP_IM2COL, cs.N, out, in, packed, buf, bias, nullptr));
+                CK(hipMemcpy(ref.data(), out, out_n * 4, hipMemcpyDeviceToHost));
+                for (size_t v = 0; v + 1 < vars.size(); ++v)
+                {
+                    CK(hipMemset(out, 0xff, out_n * 4));
+                    vars[v].second();
+                    CK(hipMemcpy(got.data(), out, out_n * 4, hipMemcpyDeviceToHost));
+                    double worst = 0;
+                    for (size_t i = 0; i < out_n; ++i) worst = std::max(worst, (double)std::abs(got[i] - ref[i]));
+                    if (!(worst <= 1e-5)) printf("      !! %s differs from the product: max |diff| %.3e\n", vars[v].first.c_str(), worst);
+                }
+            }
             std::vector<std::vector<double>> ts(vars.size());
             for (int r = 0; r < 5; ++r)
                 for (size_t v = 0; v < vars.size(); ++v)

@@ -798,7 +798,10 @@ def main():
     shard_ok = None
     if world > 1:
         if a.mode == "net":
-            shard_ok = shard_check(head_net, model, a, env)
+            try:
+                shard_ok = shard_check(head_net, model, a, env)
+            except Exception as e:  # a cross-check must never take the measured line down with it (every rank takes this path together or not at all:
+                shard_ok = {"ok": None, "error": repr(e)}  # the collectives inside are the first and last thing the ranks do in it)
         dist.barrier()
 
     if rank == 0:

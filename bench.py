@@ -223,7 +223,7 @@ def roofline_hbm(kernel, nbytes, ms, note):
 
 # kernels behind each roofline row, as rocprofv3 names them (profiles/<round>_<net>/traffic.json keys)
 TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1", "ConvGemmPolicy<2", "ConvGemmPolicy<5", "stream_gemm_kernel"),
-                   "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3", "ConvGemmPolicy<4"),
+                   "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3", "ConvGemmPolicy<4", "dwpw_band_kernel"),
                    "wino_input_transform_kernel": ("wino_input_transform_kernel", "wino43_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
 
 
@@ -429,7 +429,7 @@ def attribute(net, reps):
                                   "summed over the depthwise launches of a step (the layers fused into their 1x1 convolution have none) / sum of "
                                   "their HIP-event durations on the launch stream"))
     if fz_ms:
-        roofs.append(roofline_hbm("fused depthwise 3x3 + 1x1: gemm_mfma_kernel<ConvGemmPolicy<3|4>>", fz_bytes, fz_ms, "input of the depthwise + output "
+        roofs.append(roofline_hbm("fused depthwise 3x3 + 1x1: gemm_mfma_kernel<ConvGemmPolicy<3|4>> / dwpw_band_kernel (32-channel pair on 112-pixel rows)", fz_bytes, fz_ms, "input of the depthwise + output "
                                   "of the pointwise layer (the depthwise output never exists) summed over the fused pairs / their HIP-event durations"))
         roofs.append(roofline_mfma("fused depthwise 3x3 + 1x1 (the same launches, matrix side)", fz_flops, fz_ms, "2*K*C*Ho*Wo*N of the pointwise "
                                    "halves / the same durations"))

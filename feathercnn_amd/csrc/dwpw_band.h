@@ -1,18 +1,3 @@
-// *** EXPERIMENT (tools only, round 4) -- built, parity-green through tests/test_dwpw_gpu.py while it was wired in, measured SLOWER than
-// *** ConvGemmPolicy<3|4> and taken out of the library.  MobileNet-V1 b256 pairs, tools/dwpw_bench.py, same box, us (product route in brackets):
-// ***   all waves alternate depthwise / GEMM phases, 2 blocks per CU ............ conv3 359 [316]   conv4 391 [381]   conv5 377 [250]
-// ***   + producer / consumer waves, 1 block per CU ............................. conv3 368         conv4 493         conv5 261
-// ***   + persistent blocks (one chunk pipeline over 14 items), 8 producer waves  conv3 333         conv4 417         conv5 257
-// ***   + requests two chunk periods ahead, consumers split 128 | 96 pixels ..... conv3 367         conv4 432
-// ***   + the A panel in registers for the whole block .......................... conv3 410         conv4 434
-// *** Ablation builds of the persistent form (FHIP_BAND_ABLATE, conv4): 410 us; no depthwise arithmetic 304; no MFMAs 262; neither 194 (= the
-// *** pair's 822 MB at 4.2 TB/s); no band fetch 376.  The three costs -- HBM 194, vector ALU ~110, matrix ~150 -- stay ADDITIVE in every form:
-// *** with one 12-wave block per CU in lock step across the chip, the memory requests go out in bursts at fixed points of the chunk loop and
-// *** neither the loads nor the stores run under the arithmetic.  rocprofv3 PMC of the 8-producer form: MFMA busy 0.39, LDS pipe busy 0.39 with
-// *** 62 % of its cycles bank conflicts (before the 288-float B-tile pitch), SQ_WAIT_ANY 0.39 of wave cycles.  What the experiment DID establish
-// *** is in the ablation of the product route (tools/dwpw_ab.sh, FHIP_DWPW_ABLATE): of conv4's 381 us, ~40 are the six halo loads and ~80 the
-// *** depthwise arithmetic + masks; the GEMM-shaped route keeps 3 independent blocks per CU out of phase, which is what hides the rest.
-// *** Host glue that drove it (implicit_gemm.hip, dwpw_forward) is kept at the end of this file as a comment.
 // dwpw_band.h -- depthwise 3x3 + the 1x1 convolution behind it as ONE kernel: band-staged, wave-specialised (round 4).
 //
 // Reference functions replaced: booster::depthwise (src/booster/avx/booster.cpp:136-160, avx/depthwise.cpp) followed by IM2COL_Forward of
@@ -37,6 +22,12 @@
 //     tiles -- with the A operand straight from the streamed kernel's packed image (CH / 2 coalesced dwords per lane and chunk, a chunk ahead);
 //   * a producer and a consumer share every SIMD, so the vector ALU work of chunk i + 1 issues under the MFMAs of chunk i; ONE barrier per chunk.
 // HBM sees the pair's input once (+ the two halo rows per band, from L2) and its output once; the depthwise output never exists.
+//
+// WHERE IT IS USED (round 4, measured): the kernel is memory-parallelism bound -- a persistent block keeps at most two chunks of requests in
+// flight -- so it pays where a pair is HBM-bound and the block is small enough for TWO blocks per CU: MobileNet-V1's first pair (32 -> 64
+// channels on 112 x 112, the pair ConvGemmPolicy<3> refuses because its GEMM is 2 k-tiles deep): 406 us as two kernels -> 369 us with one
+// block per CU -> 344 us with two (tools/dwpw_bench.py, MobileNet-V1 b256).  On the 64- and 128-channel pairs every structure tried here lost
+// to ConvGemmPolicy<3|4> (tools/experiments/dwpw_band.h keeps that history and the phase-timeline instrumentation).
 #pragma once
 
 #include <type_traits>
@@ -50,17 +41,6 @@
 
 namespace fhip
 {
-
-#ifdef FHIP_BAND_TIMELINE // block 3's wave 0 of every role logs s_memtime at phase ends of its first 64 chunks: [role][chunk][4]
-__device__ unsigned long long g_band_tl[3][64][4];
-#define FHIP_TL(role, j, k)                                                                                        \
-    do                                                                                                             \
-    {                                                                                                              \
-        if (blockIdx.x == 3 && (threadIdx.x & 63) == 0 && (j) < 64 && tl_first) g_band_tl[role][(j)][(k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define FHIP_TL(role, j, k)
-#endif
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
@@ -130,9 +110,6 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
     const bool plain = wave >= SH::CW;       // (consumers) the 96-pixel group
     const int cw = plain ? wave - SH::CW : wave; // consumer index inside its group = 32-row group of output channels inside the channel block
     const int ptid = tid - 64 * 2 * SH::CW;   // producers: 0 .. PT - 1
-#ifdef FHIP_BAND_TIMELINE
-    const bool tl_first = wave == 0 || wave == SH::CW || wave == 2 * SH::CW;
-#endif
     // PERSISTENT blocks: a block takes a contiguous share of the work items (image, row group, block of output channels -- the channel blocks of
     // one band are neighbours: they read the same input band at the same time) and runs them as ONE chunk pipeline, so that the producers are
     // already two chunks into the next item while the consumers store the last one: no block start / end is ever exposed.
@@ -295,13 +272,9 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
                 // chunk j + 1's B tile (its band was completed before the last barrier), chunk j + 2's band into the buffer chunk j's left
                 // (from the request set of its parity), chunk j + 4 requested into that set
                 if (j + 1 < total_chunks) depthwise((ch + 1) % NCH);
-                FHIP_TL(2, j, 0);
                 if (j + 2 < total_chunks) stash(std::integral_constant<int, (ch + 2) % NCH>{});
-                FHIP_TL(2, j, 1);
                 if (j + 4 < total_chunks) fetch(std::integral_constant<int, ch & 1>{});
-                FHIP_TL(2, j, 2);
                 if (j + 1 < total_chunks) __syncthreads(); // B tile j + 1 and band j + 2 are complete; B tile j and band j + 1 are free
-                FHIP_TL(2, j, 3);
                 ++j;
             });
         }
@@ -379,9 +352,7 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
                         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
                     }
                 }
-                FHIP_TL(NG == 4 ? 0 : 1, j, 0);
                 if (j + 1 < total_chunks) __syncthreads();
-                FHIP_TL(NG == 4 ? 0 : 1, j, 1);
             }
 
             // ---- the item's stores (the producers are already at work on the next item's chunks).  C/D layout of the 32x32 MFMA:
@@ -433,7 +404,6 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
                     }
                 }
             }
-            FHIP_TL(NG == 4 ? 0 : 1, j - 1, 2);
 #pragma unroll
             for (int i = 0; i < NG; ++i)
 #pragma unroll
@@ -447,58 +417,3 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
 }
 
 } // namespace fhip
-
-#if 0 // ---- host glue as it stood in feathercnn_amd/csrc/implicit_gemm.hip
-// ---- the band-staged form (dwpw_band.h): which instantiation serves this pair, if any.  A block is R whole output rows x all input channels;
-// the row width, the stride and the channel count are template parameters (constant divisions, the A operand in registers), so the route exists
-// for the plane sizes it was built for -- MobileNet's 112- and 56-pixel pairs -- and everything else keeps ConvGemmPolicy<3|4> / two kernels.
-enum { kBandNone = 0, kBand112s1c32, kBand112s2c64, kBand56s1c128, kBand56s2c128 };
-//                                       W, S, R,   C, CH, consumer waves (32 output channels each), producer waves
-using Band112s1c32 = DwPwBandShape<112, 1, 2, 32, 16, 2, 4>;      // 32 -> 64 n:   2 rows of 112
-using Band112s2c64 = DwPwBandShape<112, 2, 4, 64, 8, 4, 4>;       // 64 -> 128 n:  4 rows of 56 out of 9 rows of 112
-using Band56s1c128 = DwPwBandShape<56, 1, 4, 128, 16, 4, 4>;      // 128 -> 128 n: 4 rows of 56
-using Band56s2c128 = DwPwBandShape<56, 2, 8, 128, 8, 4, 4>;       // 128 -> 128 n: 8 rows of 28 out of 17 rows of 56
-static int dwpw_band_shape(const fhip_conv_param& dw, const fhip_conv_param& pw)
-{
-#ifdef FHIP_DWPW_NO_BAND // measurement builds (tools/dwpw_ab.sh): the round-2 route only
-    return kBandNone;
-#endif
-    const int s = dw.stride_h > 0 ? dw.stride_h : 1, c = dw.input_channels, k = pw.output_channels, w = dw.input_w;
-    if (dw.pad_left != 1 || dw.pad_top != 1 || dw.stride_w != dw.stride_h || dw.output_w * s != w) return kBandNone;
-    if (w == 112 && s == 1 && c == 32 && k % 64 == 0) return kBand112s1c32;
-    if (w == 112 && s == 2 && c == 64 && k % 128 == 0) return kBand112s2c64;
-    if (w == 56 && s == 1 && c == 128 && k % 128 == 0) return kBand56s1c128;
-    if (w == 56 && s == 2 && c == 128 && k % 128 == 0) return kBand56s2c128;
-    return kBandNone;
-}
-
-template <class SH>
-static int dwpw_band_launch(const DwPwBandParams& q, int batch, hipStream_t s)
-{
-    static bool attr_set[64] = {false}; // dynamic LDS above 64 KB must be allowed once per kernel AND device
-    int dev = 0;
-    FHIP_CHECK_HIP(hipGetDevice(&dev));
-    constexpr size_t lds = (size_t)SH::LDS_FLOATS * sizeof(float);
-    if (dev < 0 || dev >= 64 || !attr_set[dev])
-    {
-        FHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_band_kernel<SH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    const long long blocks = (long long)batch * q.groups;
-    if (blocks > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N * row groups too large");
-    DwPwBandParams qq = q;
-    qq.m_tiles = q.K / (32 * SH::CW);
-    if (blocks * qq.m_tiles > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N * row groups too large");
-    qq.bands = (int)(blocks * qq.m_tiles);
-    // persistent: one block per CU (its LDS -- two bands, two B tiles, the taps -- takes most of a CU's 160 KB), each with a contiguous share
-    const int grid = std::min(qq.bands, device_compute_units());
-    hipLaunchKernelGGL((dwpw_band_kernel<SH>), dim3((unsigned)grid), dim3(SH::THREADS), lds, s, qq);
-    FHIP_CHECK_HIP(hipGetLastError());
-    return FHIP_OK;
-}
-
-
-    // in dwpw_forward, before the ConvGemmPolicy<3|4> launch:
-    //   if (const int shape = dwpw_band_shape(dw, pw)) { DwPwBandParams q = {in, g.dw_w12, g.dw_bias, pw_packed + kdp * g.Kp, pw_bias, out, batch, g.K, g.H, g.OH,
-    //                                                    g.dw_relu, g.relu}; q.groups = ceil_div(g.OH, Shape::R); return dwpw_band_launch<Shape>(q, batch, s); }
-#endif

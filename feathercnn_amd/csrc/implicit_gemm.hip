@@ -14,6 +14,7 @@
 
 #include "gemm_core.h"
 #include "conv_gemm_policy.h"
+#include "dwpw_band.h"
 #include "stream_gemm.h"
 #include "ip_stream.h"
 
@@ -400,6 +401,8 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
 
 // tile width of the small-C kernel: 32 x 4 tiles when they divide the row (a wave then stores whole 128-byte lines: VGG conv1_1
 // 0.158 vs 0.180 ms), else 16 x 8 (no wasted columns on 112-pixel rows: ResNet conv1 0.198 vs 0.223 ms)
+// (round 4, tools/variant_ab.sh: 32 x 4 tiles on 112-pixel rows too -- 128-byte instead of 64-byte output pieces, the fourth tile of a row half
+// empty -- measured: MobileNet-V1 b256 68 987 vs 69 010 images/s, ResNet-50 b64 14 334 vs 14 416: not taken)
 static int smallc_tile_w(int ow) { return (ow % 32) == 0 ? 32 : 16; }
 
 // does the small-C kernel take this geometry?  (pure function of the param: forward and the tests agree)
@@ -744,6 +747,42 @@ int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int b
 // ---- depthwise 3x3 fused into the 1x1 convolution that consumes it (MobileNet's dw -> pw pairs) -------------------------------
 // out = act_pw(W_pw * act_dw(dw3x3(in) + b_dw) + b_pw): ConvGemmPolicy<3> computes the pointwise GEMM's B operand from the depthwise
 // layer's INPUT, so the depthwise output (a tensor as large as the pair's input) is never written nor read.
+// ---- the band-staged, wave-specialised form (dwpw_band.h) for MobileNet's first pair: a 3x3 / stride-1 depthwise layer with 32 channels on
+// 112-pixel rows + a 1x1 layer with a multiple of 64 output channels.  The row width, the stride and the channel count are template parameters
+// (constant divisions, fully unrolled chunk pipeline); the other pair geometries stay on ConvGemmPolicy<3|4>, which measured faster there.
+using Band112s1c32 = DwPwBandShape<112, 1, 2, 32, 8, 2, 4, 2>; // W, S, R, C, CH, consumer waves per pixel group, producer waves, blocks per CU
+static bool dwpw_band_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw)
+{
+    const int s = dw.stride_h > 0 ? dw.stride_h : 1;
+    return dw.group == dw.input_channels && dw.kernel_h == 3 && dw.kernel_w == 3 && s == 1 && dw.stride_w == dw.stride_h && dw.pad_left == 1 &&
+           dw.pad_top == 1 && dw.input_w == 112 && dw.output_w == 112 && dw.input_channels == 32 && pw.output_channels % 64 == 0 &&
+           (dw.activation == FHIP_ACT_NONE || dw.activation == FHIP_ACT_RELU) && (pw.activation == FHIP_ACT_NONE || pw.activation == FHIP_ACT_RELU);
+}
+
+template <class SH>
+static int dwpw_band_launch(const DwPwBandParams& q, int batch, hipStream_t s)
+{
+    static bool attr_set[64] = {false}; // dynamic LDS above 64 KB must be allowed once per kernel AND device
+    int dev = 0;
+    FHIP_CHECK_HIP(hipGetDevice(&dev));
+    constexpr size_t lds = (size_t)SH::LDS_FLOATS * sizeof(float);
+    if (dev < 0 || dev >= 64 || !attr_set[dev])
+    {
+        FHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_band_kernel<SH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    DwPwBandParams qq = q;
+    qq.m_tiles = q.K / (32 * SH::CW);
+    const long long items = (long long)batch * q.groups * qq.m_tiles;
+    if (items > 0x7fffffffLL) return fail(FHIP_E_BADARG, "N * row groups too large");
+    qq.bands = (int)items;
+    // persistent: SH::BPC blocks per CU, each with a contiguous share of the (image, row group, channel block) items
+    const int grid = (int)std::min<long long>(items, (long long)device_compute_units() * SH::BPC);
+    hipLaunchKernelGGL((dwpw_band_kernel<SH>), dim3((unsigned)grid), dim3(SH::THREADS), lds, s, qq);
+    FHIP_CHECK_HIP(hipGetLastError());
+    return FHIP_OK;
+}
+
 bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch)
 {
     const int s = dw.stride_h > 0 ? dw.stride_h : 1;
@@ -761,7 +800,7 @@ bool dwpw_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw, int b
     // and K < 400 behind a stride-2 depthwise layer.  Measured on MobileNet-V1 b256: C64->K128 s2 0.374 -> 0.310 ms,
     // C128->K128 s1 0.455 -> 0.369, C128->K256 s2 0.250 -> 0.238; C256->K256 s1 0.358 -> 0.337 and C32->K64 (64-row tile, two operand
     // requests per thread) 0.414 -> 0.404 are inside the noise and stay two kernels.
-    if (pw.output_channels <= 64 || pw.output_channels >= (s == 1 ? 160 : 400)) return false;
+    if (!dwpw_band_applicable(dw, pw) && (pw.output_channels <= 64 || pw.output_channels >= (s == 1 ? 160 : 400))) return false;
     const long long ntot = (long long)batch * pw.output_h * pw.output_w;
     return batch >= 1 && ntot <= 0x7fffff00LL && !conv_narrow_n(ntot) && igemm_split(pw, batch) == 1;
 }
@@ -810,6 +849,24 @@ int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch
     g.dw_stride = dw.stride_h > 0 ? dw.stride_h : 1;
     g.dw_relu = dw.activation == FHIP_ACT_RELU;
     StageTimer tm(FHIP_STAGE_IGEMM, s);
+    if (dwpw_band_applicable(dw, pw))
+    {
+        DwPwBandParams q;
+        q.in = in;
+        q.dw_w12 = g.dw_w12;
+        q.dw_bias = g.dw_bias;
+        q.wp = pw_packed + (size_t)kdp * g.Kp; // the streamed kernel's A-operand image behind the tiled kernel's panels (igemm_init)
+        q.pw_bias = pw.bias_term ? pw_bias : nullptr;
+        q.out = out;
+        q.N = batch;
+        q.K = g.K;
+        q.H = g.H;
+        q.OH = g.OH;
+        q.dw_relu = g.dw_relu;
+        q.pw_relu = g.relu;
+        q.groups = ceil_div(g.OH, Band112s1c32::R);
+        return dwpw_band_launch<Band112s1c32>(q, batch, s);
+    }
     // three blocks per CU (168 VGPRs): the in-flight depthwise patches take 18 / 27 registers per operand request
     using FusedBig = GemmShape<128, 64, 16, 2, 2, 3>;
     if (g.dw_stride == 1) launch<FusedBig, 3>(g, s); // K > 64 (dwpw_applicable): always the 128-row tile

@@ -989,7 +989,10 @@ int ConvLayer::Fuse(Layer* next, int level)
         const fhip_conv_param& q = static_cast<ConvLayer*>(next)->p;
         if (q.group != 1 || q.kernel_h != 1 || q.kernel_w != 1 || q.stride_h != 1 || q.stride_w != 1 || q.pad_left || q.pad_right || q.pad_top || q.pad_bottom)
             return 0;
-        if (q.output_channels <= 64 || q.output_channels >= (p.stride_h == 1 ? 160 : 400)) return 0; // fhip_conv_can_fuse_dw_pw's profitable range
+        // fhip_conv_can_fuse_dw_pw's profitable range -- or the band-staged kernel's pair (32 channels, stride 1, a multiple of 64 output channels:
+        // MobileNet's first pair); the row width is only known at Reshape, where the pair falls back to its two kernels if it does not qualify
+        const bool band_pair = p.input_channels == 32 && p.stride_h == 1 && q.output_channels % 64 == 0;
+        if (!band_pair && (q.output_channels <= 64 || q.output_channels >= (p.stride_h == 1 ? 160 : 400))) return 0;
         return 2; // the pass hands `next` over (fuse_layers)
     }
     if (residual && next->type != "ReLU") return 0; // behind the residual add only its ReLU

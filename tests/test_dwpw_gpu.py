@@ -19,6 +19,10 @@ PAIRS = [(32, 96, 112, 112, 1, 2, 1, 1, 1, 1), (64, 128, 112, 112, 2, 2, 1, 1, 1
          (20, 65, 9, 8, 1, 5, 1, 1, 1, 1), (40, 72, 6, 16, 2, 3, 1, 1, 0, 1), (128, 390, 12, 24, 2, 2, 1, 1, 1, 1), (3, 130, 20, 24, 1, 1, 1, 1, 1, 1),
          # round 4: MobileNet's 112- and 56-pixel pair geometries with image heights that are not the benchmark's, no bias / no activation,
          # several blocks of output channels
+         # (32 channels on 112-pixel rows behind a stride-1 depthwise layer -- MobileNet-V1's first pair -- take the band-staged, wave-specialised
+         # kernel of dwpw_band.h: whole and partial last row groups, one and several blocks of 64 output channels, batches below / above the
+         # persistent grid, no bias / no activation)
+         (32, 64, 112, 112, 1, 2, 1, 1, 1, 1), (32, 64, 37, 112, 1, 3, 1, 1, 1, 1), (32, 192, 9, 112, 1, 1, 0, 0, 0, 0), (32, 64, 24, 112, 1, 70, 1, 1, 0, 1),
          (32, 128, 10, 112, 1, 2, 0, 1, 0, 1), (64, 128, 100, 112, 2, 2, 1, 1, 1, 1), (64, 256, 18, 112, 2, 1, 1, 0, 1, 0), (128, 128, 50, 56, 1, 2, 1, 1, 1, 1),
          (128, 128, 56, 56, 1, 2, 0, 0, 0, 0), (128, 256, 60, 56, 2, 2, 1, 1, 1, 1), (128, 384, 14, 56, 2, 1, 1, 1, 0, 1)]
 

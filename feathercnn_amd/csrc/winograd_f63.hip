@@ -380,133 +380,155 @@ struct WinoChain
     WinoLayout Lm, Lv2; // layer L's M (rows = K) and the consumer's V' (rows = K): wino_layout.h
 };
 
-// (the pooled form fits 96 registers: 5 waves per SIMD let a third 6-wave block of the 112 -> 56 px boundary on a CU, 116.6 -> 114.2 us)
-template <bool HAS_BIAS, bool RELU, bool POOL>
-__global__ __launch_bounds__(512, POOL ? 5 : 4) void wino_chain_kernel(float* __restrict__ Vn, const float* __restrict__ M, const float* __restrict__ bias,
-                                                        const WinoChain g)
+// Persistent blocks, software-pipelined over units of ppb planes (round 4).  A one-shot block is [64 loads per lane] -> A^T m A -> barrier ->
+// B^T d B -> [64 stores per lane]: its loads are in flight during the first third of its life only, and the 2 - 3 blocks of a CU drift through
+// the same stages (0.51 of the HBM rate over VGG-16's boundaries).  Here a block walks its units, and the NEXT unit's 64 M values per lane are
+// requested right after the barrier, before the current unit's windows are read out of LDS, transformed and stored: loads and stores of one
+// block overlap (64 more registers -> 3 waves per SIMD, which 3 four-wave or 2 six-wave blocks per CU fit exactly).  VGG-16 b32, same box,
+// interleaved: 1.003 -> 0.90 ms over the 12 boundaries, 9423 -> 9707 img/s.  Requesting the next tiles earlier still -- as soon as the column
+// pass has consumed m -- needs 10 more registers than 3 waves have, and the spill reloads (scratch is vmcnt-ordered behind the prefetch) bring
+// it back to the one-shot time.
+//   MULTI: a plane with more tiles than the block has lanes (224 x 224: 1444; ppb = 1) -- the lane's tiles are tid, tid + blockDim, ...; only the
+//   first one of the next unit is prefetched.
+template <bool HAS_BIAS, bool RELU, bool POOL, bool MULTI>
+__global__ __launch_bounds__(512, 3) void wino_chain_kernel(float* __restrict__ Vn, const float* __restrict__ M, const float* __restrict__ bias,
+                                                            const WinoChain g, const int units)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[]; // [ppb][LDH][LDW]
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    // consecutive blocks on the same XCD: the planes of neighbouring blocks are neighbouring column runs of M and V', which share cache lines
-    // at both ends -- they merge into whole-line traffic only inside one L2 (tools/chain_bench.py: -2 ... -9 % per boundary on VGG-16)
-    const int plane0 = xcd_remap(blockIdx.x, gridDim.x) * g.ppb;
-    const int np = min(g.ppb, g.planes - plane0);
     const int plane_floats = g.LDH * g.LDW;
     // Phase 1 writes rows 1 .. AH x columns 2 .. 2 + CW - 1 of every plane (CW = the columns layer L's tiles cover; cells beyond the image are
-    // written as zeros).  Everything else -- the consumer's padding and the slack its last tiles read -- is zeroed here; the two sets are
-    // disjoint, so there is no barrier in between and the M loads below are issued straight away.
-    {
-        const int right0 = 2 + (POOL ? 3 : 6) * g.TX, per_row = 2 + g.LDW - right0;
-        const int full_rows = g.LDH - g.AH; // row 0 and rows AH + 1 .. LDH - 1
-        for (int i = tid; i < np * full_rows * g.LDW; i += nthreads)
-        {
-            const int pl = i / (full_rows * g.LDW), r = i - pl * full_rows * g.LDW;
-            const int row = r / g.LDW, col = r - row * g.LDW;
-            smem[pl * plane_floats + (row == 0 ? 0 : g.AH + row) * g.LDW + col] = 0.f;
-        }
-        for (int i = tid; i < np * g.AH * per_row; i += nthreads)
-        {
-            const int pl = i / (g.AH * per_row), r = i - pl * g.AH * per_row;
-            const int y = r / per_row, e = r - y * per_row;
-            smem[pl * plane_floats + (y + 1) * g.LDW + (e < 2 ? e : right0 + e - 2)] = 0.f;
-        }
-    }
+    // written as zeros) and nothing else: the consumer's padding and the slack its last tiles read are zeroed once per block
+    for (int i = tid; i < g.ppb * plane_floats; i += nthreads) smem[i] = 0.f;
+    const int n1 = MULTI ? (g.T + nthreads - 1) / nthreads : 1;
+    int pl = MULTI ? 0 : tid / g.T, t = tid - pl * g.T; // phase 1: layer L's tile (ty, tx) of plane pl of the unit
+    bool lane_on = MULTI ? t < g.T : pl < g.ppb;
+    int ty = t / g.TX, tx = t - ty * g.TX;
+    const int pl2 = tid / g.T2, t2 = tid - pl2 * g.T2; // phase 2: the consumer's tile
+    const bool lane_on2 = pl2 < g.ppb;
+    const int ty2 = t2 / g.TX2, tx2 = t2 - ty2 * g.TX2;
+    // unit order: the XCD blockIdx % 8 owns a contiguous eighth of the units, and its blocks take neighbouring units at the same time -- their
+    // column runs of M and V' share cache lines at both ends, which merge into whole-line traffic only inside one L2 (tools/chain_bench.py:
+    // -2 ... -9 % per boundary on VGG-16)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, xcd_blocks = (gridDim.x + 7 - xcd) >> 3;
+    const int u_lo = (int)((long long)units * xcd / 8), u_hi = (int)((long long)units * (xcd + 1) / 8);
+    const size_t xi_stride = g.Lm.xis, xi_stride2 = g.Lv2.xis;
+    float* const lp1 = smem + pl * plane_floats;
 
-    // ---- phase 1: layer L's tiles -> activation plane(s) in LDS
-    const size_t xi_stride = g.Lm.xis;
-    for (int w = tid; w < np * g.T; w += nthreads)
-    {
-        const int pl = w / g.T, t = w - pl * g.T;
-        const int plane = plane0 + pl;
+    float m[8][8];
+    auto fetch = [&](int unit, int tile) {
+        // clamped and unconditional (a load under a branch is waited for on the spot)
+        const int plane = min(unit * g.ppb + (lane_on ? pl : 0), g.planes - 1);
         const int k = plane / g.N, n = plane - k * g.N;
-        const int ty = t / g.TX, tx = t - ty * g.TX;
-        const float* mp = M + (size_t)k * g.Lm.bp + g.Lm.col(n * g.T + t);
-        float m[8][8];
+        const float* mp = M + (size_t)k * g.Lm.bp + g.Lm.col(n * g.T + min(tile, g.T - 1));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[i][j] = mp[(size_t)(i * 8 + j) * xi_stride];
-        float tmp[6][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            at6(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], m[6][j], m[7][j], tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j], tmp[4][j], tmp[5][j]);
-        const float b = HAS_BIAS ? bias[k] : 0.f;
-        float* lp = smem + pl * plane_floats;
-        float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int jj = 0; jj < 8; ++jj) m[i][jj] = mp[(size_t)(i * 8 + jj) * xi_stride];
+    };
+    int unit = u_lo + j;
+    if (unit < u_hi) fetch(unit, t);
+    __syncthreads();
+    for (; unit < u_hi; unit += xcd_blocks)
+    {
+        const int plane = unit * g.ppb + pl;
+        const int k = min(plane, g.planes - 1) / g.N;
+        // ---- phase 1: layer L's tiles -> activation plane(s) in LDS
+        for (int it = 0; it < n1; ++it)
         {
-            float y[6];
-            at6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], tmp[a][6], tmp[a][7], y[0], y[1], y[2], y[3], y[4], y[5]);
-#pragma unroll
-            for (int bb = 0; bb < 6; ++bb)
+            if (MULTI)
             {
-                float v = y[bb] + b;
-                if (RELU) v = fmaxf(v, 0.f);
-                y[bb] = v;
+                t = tid + it * nthreads;
+                lane_on = t < g.T;
+                ty = t / g.TX;
+                tx = t - ty * g.TX;
             }
-            if (POOL)
+            if (lane_on && plane < g.planes)
             {
-                // OH, OW even: a 2x2 cell never straddles the image edge; a whole cell is inside or outside
-                const float h0 = fmaxf(y[0], y[1]), h1 = fmaxf(y[2], y[3]), h2 = fmaxf(y[4], y[5]);
-                if ((a & 1) == 0)
+                float tmp[6][8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    at6(m[0][jj], m[1][jj], m[2][jj], m[3][jj], m[4][jj], m[5][jj], m[6][jj], m[7][jj], tmp[0][jj], tmp[1][jj], tmp[2][jj], tmp[3][jj],
+                        tmp[4][jj], tmp[5][jj]);
+                const float b = HAS_BIAS ? bias[k] : 0.f;
+                float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
                 {
-                    prev0 = h0;
-                    prev1 = h1;
-                    prev2 = h2;
-                }
-                else
-                {
-                    const int ay = 3 * ty + (a >> 1);
+                    float y[6];
+                    at6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], tmp[a][6], tmp[a][7], y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+                    for (int bb = 0; bb < 6; ++bb)
+                    {
+                        float v = y[bb] + b;
+                        if (RELU) v = fmaxf(v, 0.f);
+                        y[bb] = v;
+                    }
+                    if (POOL)
+                    {
+                        // OH, OW even: a 2x2 cell never straddles the image edge; a whole cell is inside or outside
+                        const float h0 = fmaxf(y[0], y[1]), h1 = fmaxf(y[2], y[3]), h2 = fmaxf(y[4], y[5]);
+                        if ((a & 1) == 0)
+                        {
+                            prev0 = h0;
+                            prev1 = h1;
+                            prev2 = h2;
+                        }
+                        else
+                        {
+                            const int ay = 3 * ty + (a >> 1);
+                            if (ay < g.AH)
+                            {
+                                float* row = lp1 + (size_t)(ay + 1) * g.LDW + 2 + 3 * tx;
+                                row[0] = (3 * tx < g.AW) ? fmaxf(prev0, h0) : 0.f;
+                                row[1] = (3 * tx + 1 < g.AW) ? fmaxf(prev1, h1) : 0.f;
+                                row[2] = (3 * tx + 2 < g.AW) ? fmaxf(prev2, h2) : 0.f;
+                            }
+                        }
+                        continue;
+                    }
+                    const int ay = 6 * ty + a;
                     if (ay < g.AH)
                     {
-                        float* row = lp + (size_t)(ay + 1) * g.LDW + 2 + 3 * tx;
-                        row[0] = (3 * tx < g.AW) ? fmaxf(prev0, h0) : 0.f;
-                        row[1] = (3 * tx + 1 < g.AW) ? fmaxf(prev1, h1) : 0.f;
-                        row[2] = (3 * tx + 2 < g.AW) ? fmaxf(prev2, h2) : 0.f;
+                        float* row = lp1 + (size_t)(ay + 1) * g.LDW + 2 + 6 * tx; // even offset: 8-byte aligned pairs
+#pragma unroll
+                        for (int bb = 0; bb < 6; bb += 2)
+                        {
+                            const float v0 = (6 * tx + bb < g.AW) ? y[bb] : 0.f, v1 = (6 * tx + bb + 1 < g.AW) ? y[bb + 1] : 0.f;
+                            *reinterpret_cast<float2*>(row + bb) = make_float2(v0, v1);
+                        }
                     }
                 }
-                continue;
             }
-            const int ay = 6 * ty + a;
-            if (ay < g.AH)
-            {
-                float* row = lp + (size_t)(ay + 1) * g.LDW + 2 + 6 * tx; // even offset: 8-byte aligned pairs
-#pragma unroll
-                for (int bb = 0; bb < 6; bb += 2)
-                {
-                    const float v0 = (6 * tx + bb < g.AW) ? y[bb] : 0.f, v1 = (6 * tx + bb + 1 < g.AW) ? y[bb + 1] : 0.f;
-                    *reinterpret_cast<float2*>(row + bb) = make_float2(v0, v1);
-                }
-            }
+            if (MULTI && it + 1 < n1) fetch(unit, tid + (it + 1) * nthreads);
         }
-    }
-    __syncthreads();
-
-    // ---- phase 2: the consumer's tiles: window rows 6ty-1 .. 6ty+6, columns 6tx-1 .. 6tx+6 of the activation = LDS rows 6ty .. 6ty+7,
-    // columns 6tx+1 .. 6tx+8 (one border row on top, two border columns on the left)
-    const size_t xi_stride2 = g.Lv2.xis;
-    for (int w = tid; w < np * g.T2; w += nthreads)
-    {
-        const int pl = w / g.T2, t = w - pl * g.T2;
-        const int plane = plane0 + pl;
-        const int k = plane / g.N, n = plane - k * g.N;
-        const int ty = t / g.TX2, tx = t - ty * g.TX2;
-        const float* lp = smem + pl * plane_floats + (size_t)(6 * ty) * g.LDW + 6 * tx + 1;
-        float d[8][8];
+        __syncthreads();
+        // ---- the next unit's tiles: in flight through phase 2
+        if (unit + xcd_blocks < u_hi) fetch(unit + xcd_blocks, MULTI ? tid : t);
+        __builtin_amdgcn_sched_barrier(0); // hipcc would sink the loads to their uses
+        // ---- phase 2: the consumer's tiles: window rows 6ty-1 .. 6ty+6, columns 6tx-1 .. 6tx+6 of the activation = LDS rows 6ty .. 6ty+7,
+        // columns 6tx+1 .. 6tx+8 (one border row on top, two border columns on the left)
+        const int plane2 = unit * g.ppb + pl2;
+        if (lane_on2 && plane2 < g.planes)
+        {
+            const int k2 = plane2 / g.N, n2 = plane2 - k2 * g.N;
+            const float* lp = smem + pl2 * plane_floats + (size_t)(6 * ty2) * g.LDW + 6 * tx2 + 1;
+            float d[8][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[i][j] = lp[(size_t)i * g.LDW + j];
+                for (int jj = 0; jj < 8; ++jj) d[i][jj] = lp[(size_t)i * g.LDW + jj];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bt8(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
+            for (int jj = 0; jj < 8; ++jj) bt8(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj], d[6][jj], d[7][jj]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
-        float* vp = Vn + (size_t)k * g.Lv2.bp + g.Lv2.col(n * g.T2 + t);
+            for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
+            float* vp = Vn + (size_t)k2 * g.Lv2.bp + g.Lv2.col(n2 * g.T2 + t2);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * xi_stride2] = d[i][j];
+                for (int jj = 0; jj < 8; ++jj) vp[(size_t)(i * 8 + jj) * xi_stride2] = d[i][jj];
+        }
+        __syncthreads(); // the windows are read: the next phase 1 may overwrite the planes
     }
 }
 
@@ -1028,11 +1050,23 @@ int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_para
     int ppb = std::max(1, 256 / work);
     ppb = (int)std::min<size_t>(ppb, std::max<size_t>(1, (48 * 1024) / plane_bytes));
     g.ppb = (int)std::min<long long>(ppb, planes);
-    const unsigned threads = work > 256 ? (unsigned)std::min(512, (work + 63) / 64 * 64) : 256u;
+    // phase 2 always has a lane per tile (can_chain's 64 KB plane holds at most 455 consumer tiles); phase 1 too, except behind the fused pooling
+    // on planes of more than 512 tiles (224 x 224), whose block is sized for phase 2 and loops in phase 1
+    const bool multi = work > 512;
+    const unsigned threads = std::max(256u, (unsigned)((multi ? g.T2 : work) + 63) / 64 * 64);
+    if (threads > 512u) return fail(FHIP_E_UNSUPPORTED, "chained transform: the consumer's plane has more than 512 tiles");
     const size_t lds = plane_bytes * g.ppb;
-    const unsigned grid = (unsigned)((planes + g.ppb - 1) / g.ppb);
+    const long long units = (planes + g.ppb - 1) / g.ppb;
+    // persistent: what is resident at 3 waves per SIMD (12 waves per CU) and 160 KB of LDS, a multiple of 8 so that every XCD runs the same count
+    const int bpc = std::max(1, std::min((int)((160 * 1024) / lds), 12 / (int)(threads / 64)));
+    const unsigned grid = ((unsigned)std::min<long long>(units, (long long)device_compute_units() * bpc) + 7u) & ~7u;
     StageTimer tm(FHIP_STAGE_WINO_CHAIN, s);
-#define FHIP_CHAIN(B_, R_, P_) hipLaunchKernelGGL((wino_chain_kernel<B_, R_, P_>), dim3(grid), dim3(threads), lds, s, vn, m, bias, g)
+#define FHIP_CHAIN(B_, R_, P_)                                                                                                                       \
+    do                                                                                                                                               \
+    {                                                                                                                                                \
+        if (multi) hipLaunchKernelGGL((wino_chain_kernel<B_, R_, P_, true>), dim3(grid), dim3(threads), lds, s, vn, m, bias, g, (int)units);        \
+        else hipLaunchKernelGGL((wino_chain_kernel<B_, R_, P_, false>), dim3(grid), dim3(threads), lds, s, vn, m, bias, g, (int)units);             \
+    } while (0)
     if (pool)
     {
         if (has_bias && relu) FHIP_CHAIN(true, true, true);

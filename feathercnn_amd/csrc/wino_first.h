@@ -30,6 +30,7 @@ struct WinoFirstParams
     int K, H, W;       // first layer: H x W in and out
     int TX, T, P, Pp;  // the consumer's tiling
     unsigned in_bytes; // < 2^30 (the out-of-range encoding below)
+    unsigned v_bytes;  // all of V, for the shared-column form's buffer stores (<= 2^31, else that form is not used)
     int relu;
     int N, bpi;        // staged form: images, blocks per image (64 tiles each)
     int LDW, rows;     // staged form: LDS row pitch 6 TX + 4 and the most patch rows a block stages
@@ -169,9 +170,18 @@ constexpr bool kFirstHoist = true;
 constexpr bool kFirstXcd = true;
 constexpr int kFirstTiles = 64; // tiles per block
 
-template <int CIN, int CPB = kFirstCpb, bool HOIST = kFirstHoist, int WAVES = kFirstWaves, bool XCD = kFirstXcd>
+//
+// SHARE (round 4): horizontally adjacent windows overlap in two columns -- a lane's columns 6, 7 are its right neighbour's columns 0, 1, the same
+// first-layer values behind the same row clamps.  A lane computes columns 0 .. 5 only (1296 FMAs instead of 1728, 40 LDS reads per image channel
+// instead of 50) and takes the other two from lane + 1 (16 ds_bpermute per channel).  The row-end tile has no right neighbour and needs none
+// when its columns 6, 7 lie outside the image (6 TX - 1 >= W: the launcher's condition -- they are the consumer's zero padding); the wave-end
+// lane has none either, so a block owns 63 tiles and lane 63 computes the 64th for its neighbour's sake only (no stores; ceil(T / 63) blocks per
+// image: 23 either way at 224 px).  Same values, same order of summation.
+template <int CIN, bool SHARE, int CPB = kFirstCpb, bool HOIST = kFirstHoist, int WAVES = kFirstWaves, bool XCD = kFirstXcd>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_staged_kernel(const WinoFirstParams q)
 {
+    constexpr int TPB = SHARE ? kFirstTiles - 1 : kFirstTiles; // tiles a block stores
+    constexpr int NC = SHARE ? 6 : 8;                          // window columns a lane computes
     extern __shared__ __attribute__((aligned(16))) float smem[]; // [CIN][rows][LDW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive tile blocks on the same XCD: their 256-byte V runs share cache lines at both ends (p = n T + t is 16-byte aligned at
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
     const int lin = XCD ? xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
     const int bx = lin % gridDim.x, by = lin / gridDim.x;
     const int n = bx / q.bpi, b = bx - n * q.bpi;
-    const int t0 = b * kFirstTiles, nt = min(kFirstTiles, q.T - t0);
+    const int t0 = b * TPB, nt = min(TPB, q.T - t0);
     const int ty0 = t0 / q.TX, ty1 = (t0 + nt - 1) / q.TX;
     const int rows = 6 * (ty1 - ty0 + 1) + 4; // image rows 6 ty0 - 2 ... 6 ty1 + 7
     const int ry0 = 6 * ty0 - 2;
@@ -210,8 +220,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
         }
     }
     __syncthreads();
-    if (lane >= nt) return;
-    const int t = t0 + lane;
+    // SHARE: lane 63 of a full block is the helper -- the tile after the block's last one if that is its right neighbour, else (next tile row,
+    // or none: the last tile's columns 6, 7 are padding) a copy of the last one whose values nobody takes
+    const bool helper = SHARE && lane == TPB && nt == TPB;
+    if (lane >= nt && !helper) return;
+    int t = t0 + lane;
+    if (helper && (t >= q.T || t % q.TX == 0)) t -= 1;
     const int ty = t / q.TX, tx = t - ty * q.TX;
     const int y0 = 6 * ty - 1, x0 = 6 * tx - 1;
     const float* patch = smem + (size_t)(6 * (ty - ty0)) * q.LDW + 6 * tx; // image (6 ty - 2, 6 tx - 2)
@@ -221,6 +235,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
     const int p_lane = n * q.T + t, p_first = __builtin_amdgcn_readfirstlane(n * q.T + t0);
     const size_t col_first = q.Lv.col(p_first);
     const unsigned lane_off = (unsigned)(q.Lv.col(p_lane) - col_first);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(q.V, 0, (int)q.v_bytes, 0x00020000);
+    const unsigned voff = helper ? 0x80000000u : lane_off * 4u;
     const float lo = q.relu ? 0.f : -__builtin_huge_valf();
     // activation + the consumer's zero padding in two instructions per value: clamp(a, lo_i, hi_i) with [lo_i, hi_i] = [lo, inf) on rows of the
     // window inside the image and [0, 0] outside, then a select on the column (64 precomputed (row, column) lane masks would not fit the
@@ -248,29 +264,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
 #pragma unroll
                 for (int v = 0; v < 3; ++v) w[c][u][v] = q.w[((size_t)k * CIN + c) * 9 + u * 3 + v];
         const float bias = q.bias ? q.bias[k] : 0.f;
-        float acc[8][8];
+        float acc[8][NC];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = bias;
+            for (int j = 0; j < NC; ++j) acc[i][j] = bias;
 #pragma unroll
         for (int c = 0; c < CIN; ++c)
         {
             // the whole 10 x 10 patch of this image channel is requested before its first FMA (100 registers; 2 waves per SIMD leave 256):
             // one LDS round trip per image channel instead of one per patch row
             const float* pc = patch + (size_t)c * q.rows * q.LDW;
-            f32x2 pr[10][5];
+            if (SHARE) __builtin_amdgcn_sched_barrier(0); // ... and would hoist the next channel's reads over this one's FMAs (spills)
+            f32x2 pr[10][NC / 2 + 1];
 #pragma unroll
             for (int r = 0; r < 10; ++r)
 #pragma unroll
-                for (int m = 0; m < 5; ++m) pr[r][m] = *reinterpret_cast<const f32x2*>(pc + (size_t)r * q.LDW + 2 * m);
+                for (int m = 0; m < NC / 2 + 1; ++m) pr[r][m] = *reinterpret_cast<const f32x2*>(pc + (size_t)r * q.LDW + 2 * m);
             if (HOIST) __builtin_amdgcn_sched_barrier(0); // hipcc otherwise sinks the reads to their uses: 76 waits per channel instead of a counted few
 #pragma unroll
             for (int r = 0; r < 10; ++r)
             {
-                float row[10];
+                float row[NC + 2];
 #pragma unroll
-                for (int m = 0; m < 5; ++m)
+                for (int m = 0; m < NC / 2 + 1; ++m)
                 {
                     row[2 * m] = pr[r][m].x;
                     row[2 * m + 1] = pr[r][m].y;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
 #pragma unroll
                     for (int v = 0; v < 3; ++v)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(w[c][u][v], row[j + v], acc[i][j]);
+                        for (int j = 0; j < NC; ++j) acc[i][j] = fmaf(w[c][u][v], row[j + v], acc[i][j]);
                 }
             }
         }
@@ -291,20 +308,45 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < NC; ++j)
             {
                 d[i][j] = colok[j] ? __builtin_amdgcn_fmed3f(acc[i][j], row_lo[i], row_hi[i]) : 0.f;
             }
+        if (SHARE)
+        {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const float n0 = __shfl_down(d[i][0], 1), n1 = __shfl_down(d[i][1], 1);
+                d[i][6] = colok[6] ? n0 : 0.f;
+                d[i][7] = colok[7] ? n1 : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) bt8(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
         // wave-uniform base (scalar registers) + the lane's tile index: no 64-bit vector address arithmetic per store
-        float* vb = q.V + (size_t)k * q.Lv.bp + col_first;
+        if (SHARE)
+        {
+            // buffer stores (V is at most 2 GiB here): the helper's offset lies beyond num_records, so the hardware drops its stores -- a branch
+            // around the 64 stores costs hipcc 57 more registers than the kernel has
+            const unsigned sbase = (unsigned)(((size_t)k * q.Lv.bp + col_first) * sizeof(float));
+            const unsigned sstep = (unsigned)(xi_stride * sizeof(float));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
+                for (int j = 0; j < 8; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[i][j]), vrsrc, (int)voff, (int)(sbase + (unsigned)(i * 8 + j) * sstep), 0);
+        }
+        else
+        {
+            float* vb = q.V + (size_t)k * q.Lv.bp + col_first;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
+        }
     }
 }
 

@@ -840,24 +840,40 @@ int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_para
     q.in_bytes = (unsigned)(4ull * batch * first.input_channels * first.input_h * first.input_w);
     q.relu = first.activation == FHIP_ACT_RELU;
     StageTimer tm(FHIP_STAGE_WINO_INPUT, s);
-    // staged form: 64 consecutive tiles of an image span at most floor((TX + 62) / TX) + 1 tile rows
+    // staged form: 64 (63 with shared columns) consecutive tiles of an image span at most floor((TX + 62) / TX) + 1 tile rows
     q.N = batch;
-    q.bpi = ceil_div(q.T, kFirstTiles);
+    const unsigned long long v_bytes = 64ull * q.K * q.Pp * sizeof(float);
+    // the row-end tile's columns 6, 7 are padding, and V is within reach of 32-bit buffer offsets (wino_first.h)
+#ifdef FHIP_FIRST_NOSHARE
+    const bool share = false;
+#else
+    const bool share = 6 * q.TX - 1 >= q.W && v_bytes <= 0x80000000ull;
+#endif
+    q.v_bytes = share ? (unsigned)v_bytes : 0u;
+    const int tpb = share ? kFirstTiles - 1 : kFirstTiles;
+    q.bpi = ceil_div(q.T, tpb);
     q.LDW = 6 * q.TX + 4;
     q.rows = 6 * std::min(pl.tiles_y, (q.TX + kFirstTiles - 2) / q.TX + 1) + 4;
     const size_t lds = (size_t)first.input_channels * q.rows * q.LDW * sizeof(float);
     // the staged form gives every image blocks of its own: below 3/4 full lanes (small planes: 14 x 14 has 9 tiles) the direct form,
     // whose lanes run across images, is the better one
-    const bool lanes_full = 4 * q.T >= 3 * q.bpi * kFirstTiles;
+    const bool lanes_full = 4 * q.T >= 3 * q.bpi * tpb;
     if (lanes_full && lds <= 64 * 1024 && q.LDW <= 256 && (long long)q.bpi * batch <= 0x7fffffffLL) // 128 float2 columns: one per thread pair
     {
         const dim3 grid((unsigned)(q.bpi * batch), (unsigned)ceil_div(q.K, kFirstCpb));
+#define FHIP_FIRST(C_)                                                                                                \
+    do                                                                                                                \
+    {                                                                                                                 \
+        if (share) hipLaunchKernelGGL((wino_input_from_first_staged_kernel<C_, true>), grid, dim3(256), lds, s, q);  \
+        else hipLaunchKernelGGL((wino_input_from_first_staged_kernel<C_, false>), grid, dim3(256), lds, s, q);       \
+    } while (0)
         switch (first.input_channels)
         {
-            case 2: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<2>, grid, dim3(256), lds, s, q); break;
-            case 3: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<3>, grid, dim3(256), lds, s, q); break;
-            default: hipLaunchKernelGGL(wino_input_from_first_staged_kernel<4>, grid, dim3(256), lds, s, q); break;
+            case 2: FHIP_FIRST(2); break;
+            case 3: FHIP_FIRST(3); break;
+            default: FHIP_FIRST(4); break;
         }
+#undef FHIP_FIRST
         FHIP_CHECK_HIP(hipGetLastError());
         return FHIP_OK;
     }

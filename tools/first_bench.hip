@@ -78,11 +78,11 @@ int main(int argc, char** argv)
     {
         double t[6];
         t[0] = time_us([&] { hipLaunchKernelGGL(wino_input_from_first_kernel<3>, dim3((unsigned)((P + 255) / 256), K), dim3(256), 0, 0, q); });
-        t[1] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true>), dim3(gx, K / 16), dim3(256), lds, 0, q); });
-        t[2] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 32, true>), dim3(gx, K / 32), dim3(256), lds, 0, q); });
-        t[3] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 32, false>), dim3(gx, K / 32), dim3(256), lds, 0, q); });
-        t[4] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 32, false, 8>), dim3(gx, K / 32), dim3(512), lds, 0, q); });
-        t[5] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 64, false, 8>), dim3(gx, K / 64), dim3(512), lds, 0, q); });
+        t[1] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 16, true>), dim3(gx, K / 16), dim3(256), lds, 0, q); });
+        t[2] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 32, true>), dim3(gx, K / 32), dim3(256), lds, 0, q); });
+        t[3] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 32, false>), dim3(gx, K / 32), dim3(256), lds, 0, q); });
+        t[4] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 32, false, 8>), dim3(gx, K / 32), dim3(512), lds, 0, q); });
+        t[5] = time_us([&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 64, false, 8>), dim3(gx, K / 64), dim3(512), lds, 0, q); });
         CK(hipGetLastError());
         if (r)
             for (int i = 0; i < 6; ++i) vars[i].t.push_back(t[i]);
@@ -98,13 +98,13 @@ int main(int argc, char** argv)
     const size_t vbytes = (size_t)64 * K * Pp * 4;
     CK(hipMalloc(&dst, vbytes));
     auto copy = [&] { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, dst, (const float4*)V, vbytes / 16); };
-    auto staged = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, false>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
-    auto staged_xcd = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
+    auto staged = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 16, true, 4, false>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
+    auto staged_xcd = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q); };
     float* V2;
     CK(hipMalloc(&V2, vbytes));
     WinoFirstParams q2 = q;
     q2.V = V2;
-    auto staged_other = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q2); };
+    auto staged_other = [&] { hipLaunchKernelGGL((wino_input_from_first_staged_kernel<3, false, 16, true, 4, true>), dim3(gx, K / 16), dim3(256), lds, 0, q2); };
     auto copy_back = [&] { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, (float4*)V, (const float4*)dst, vbytes / 16); };
     auto direct = [&] { hipLaunchKernelGGL(wino_input_from_first_kernel<3>, dim3((unsigned)((P + 255) / 256), K), dim3(256), 0, 0, q); };
     struct Seq { const char* name; std::vector<double> t; } seqs[] = {{"copy after copy", {}}, {"copy after staged", {}}, {"copy after staged + 100 us idle", {}},

@@ -152,25 +152,38 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(float* __restrict__ y, 
         const int ox = xq * 4, ix = ox * 2;
         const float* xp = x + plane * H * W;
         float m0 = -FLT_MAX, m1 = -FLT_MAX, m2 = -FLT_MAX, m3 = -FLT_MAX;
+        // all nine loads unconditional, from clamped addresses (a load under a branch is waited for on the spot): a row past the image repeats
+        // the last one (the maximum does not change), columns past it are replaced by -FLT_MAX after the load
+        const bool has_b = ix + 4 < W, has_c = ix + 8 < W;
+        float4 a[3], b[3];
+        float c[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
         {
-            const int iy = oy * 2 + r;
-            if (iy >= H) break;
-            const float* row = xp + (size_t)iy * W + ix;
-            const float4 a = *reinterpret_cast<const float4*>(row);                                  // ix + 3 < W always (W % 4 == 0)
-            const float4 b = ix + 4 < W ? *reinterpret_cast<const float4*>(row + 4) : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-            const float c = ix + 8 < W ? row[8] : -FLT_MAX;
-            m0 = fmaxf(m0, fmaxf(fmaxf(a.x, a.y), a.z));
-            m1 = fmaxf(m1, fmaxf(fmaxf(a.z, a.w), b.x));
-            m2 = fmaxf(m2, fmaxf(fmaxf(b.x, b.y), b.z));
-            m3 = fmaxf(m3, fmaxf(fmaxf(b.z, b.w), c));
+            const float* row = xp + (size_t)min(oy * 2 + r, H - 1) * W + ix;
+            a[r] = *reinterpret_cast<const float4*>(row); // ix + 3 < W always (W % 4 == 0)
+            b[r] = *reinterpret_cast<const float4*>(row + (has_b ? 4 : 0));
+            c[r] = row[has_c ? 8 : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+        {
+            if (!has_b) b[r] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+            if (!has_c) c[r] = -FLT_MAX;
+            m0 = fmaxf(m0, fmaxf(fmaxf(a[r].x, a[r].y), a[r].z));
+            m1 = fmaxf(m1, fmaxf(fmaxf(a[r].z, a[r].w), b[r].x));
+            m2 = fmaxf(m2, fmaxf(fmaxf(b[r].x, b[r].y), b[r].z));
+            m3 = fmaxf(m3, fmaxf(fmaxf(b[r].z, b[r].w), c[r]));
         }
         float* yp = y + (plane * OH + oy) * OW + ox;
-        yp[0] = m0;
-        if (ox + 1 < OW) yp[1] = m1;
-        if (ox + 2 < OW) yp[2] = m2;
-        if (ox + 3 < OW) yp[3] = m3;
+        if ((OW & 3) == 0) *reinterpret_cast<float4*>(yp) = make_float4(m0, m1, m2, m3); // whole, aligned quads
+        else
+        {
+            yp[0] = m0;
+            if (ox + 1 < OW) yp[1] = m1;
+            if (ox + 2 < OW) yp[2] = m2;
+            if (ox + 3 < OW) yp[3] = m3;
+        }
     }
 }
 

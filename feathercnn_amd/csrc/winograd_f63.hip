@@ -533,6 +533,101 @@ __global__ __launch_bounds__(512, 3) void wino_chain_kernel(float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2 staged (round 4): the input transform of a 3x3 / stride-1 / pad-1 layer on planes that fit the LDS, in the chained kernel's form -- a
+// block walks units of ppb (image, channel) planes; a plane comes in as whole 16-byte vectors (NV per lane and unit, the next unit's requested
+// before this one's windows are read) and is written into the zero-bordered LDS plane, phase 2 is the chained kernel's.  wino_input_transform_
+// kernel reads its 8 x 8 window straight from the image: 64 dword loads per lane at a 24-byte lane stride, 12 cache lines per load, most
+// lanes of ResNet-50's 56 / 28 / 14-px planes on the bounds-checked path.  Same butterflies on the same values: bit-identical V.
+template <int NV>
+__global__ __launch_bounds__(512, 3) void wino_input_staged_kernel(float* __restrict__ Vn, const float* __restrict__ in, const WinoChain g,
+                                                                   const int units)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[]; // [ppb][LDH][LDW]
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int plane_floats = g.LDH * g.LDW;
+    for (int i = tid; i < g.ppb * plane_floats; i += nthreads) smem[i] = 0.f; // borders stay zero: the copies below write the interior only
+    const int hw = g.AH * g.AW, hw4 = hw >> 2, unit4 = g.ppb * hw4; // hw % 4 == 0 (launcher)
+    const int pl2 = tid / g.T2, t2 = tid - pl2 * g.T2;
+    const bool lane_on2 = pl2 < g.ppb;
+    const int ty2 = t2 / g.TX2, tx2 = t2 - ty2 * g.TX2;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, xcd_blocks = (gridDim.x + 7 - xcd) >> 3; // unit order: as wino_chain_kernel
+    const int u_lo = (int)((long long)units * xcd / 8), u_hi = (int)((long long)units * (xcd + 1) / 8);
+    const size_t xi_stride2 = g.Lv2.xis;
+
+    // the lane's NV vectors of a unit: vector e = tid + v * nthreads of the unit's ppb * hw4 (clamped: the loads stay unconditional)
+    int e_pl[NV], e_q[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+    {
+        const int e = min(tid + v * nthreads, unit4 - 1);
+        e_pl[v] = e / hw4;
+        e_q[v] = e - e_pl[v] * hw4;
+    }
+    float4 r[NV];
+    auto fetch = [&](int unit) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+        {
+            const int plane = min(unit * g.ppb + e_pl[v], g.planes - 1);
+            const int k = plane / g.N, n = plane - k * g.N;
+            r[v] = *reinterpret_cast<const float4*>(in + ((size_t)n * g.K + k) * hw + 4 * e_q[v]);
+        }
+    };
+    int unit = u_lo + j;
+    if (unit < u_hi) fetch(unit);
+    __syncthreads();
+    for (; unit < u_hi; unit += xcd_blocks)
+    {
+        // ---- phase 1: the planes' pixels -> LDS rows 1 .. AH, columns 2 .. AW + 1
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+        {
+            if (tid + v * nthreads < unit4)
+            {
+                int y = (4 * e_q[v]) / g.AW, x = 4 * e_q[v] - y * g.AW;
+                float* lp = smem + e_pl[v] * plane_floats;
+                const float val[4] = {r[v].x, r[v].y, r[v].z, r[v].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    lp[(y + 1) * g.LDW + 2 + x] = val[c];
+                    if (++x == g.AW)
+                    {
+                        x = 0;
+                        ++y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (unit + xcd_blocks < u_hi) fetch(unit + xcd_blocks);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2: as wino_chain_kernel
+        const int plane2 = unit * g.ppb + pl2;
+        if (lane_on2 && plane2 < g.planes)
+        {
+            const int k2 = plane2 / g.N, n2 = plane2 - k2 * g.N;
+            const float* lp = smem + pl2 * plane_floats + (size_t)(6 * ty2) * g.LDW + 6 * tx2 + 1;
+            float d[8][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) d[i][jj] = lp[(size_t)i * g.LDW + jj];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) bt8(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj], d[6][jj], d[7][jj]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bt8(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7]);
+            float* vp = Vn + (size_t)k2 * g.Lv2.bp + g.Lv2.col(n2 * g.T2 + t2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) vp[(size_t)(i * 8 + jj) * xi_stride2] = d[i][jj];
+        }
+        __syncthreads(); // the windows are read: the next copies may overwrite the planes
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // F(4x4, 3x3) for planes of 7 or 8 output pixels per side (round 4; ResNet-50's res5 3x3 layers).  The reference sends such layers to
 // IM2COL (avx/booster.cpp:289: h, w <= 8); this library's tuned rule runs them as Winograd, and on a 7 x 7 plane F(6x6,3x3) needs 2 x 2 tiles
 // of 6 x 6 outputs -- 144 computed for 49 used -- with 64 frequency points each.  2 x 2 tiles of 4 x 4 outputs cover 8 x 8 with 36 frequency
@@ -780,6 +875,59 @@ int winograd_transform_kernel(const fhip_conv_param& p, float* u, const float* k
     return FHIP_OK;
 }
 
+// The staged input transform where it applies (pad 1 all round, whole 16-byte vectors per plane, a plane within 48 KB of LDS, at most 7 vectors
+// per lane and unit); false = not launched.
+static bool winograd_input_staged(const fhip_conv_param& p, int batch, const fhip_winograd_plan& pl, float* v, const float* input, hipStream_t s)
+{
+#ifdef FHIP_K2_DIRECT
+    return false;
+#endif
+    if (p.pad_left != 1 || p.pad_top != 1 || p.pad_right != 1 || p.pad_bottom != 1) return false;
+    const int hw = p.input_h * p.input_w;
+    if (hw & 3) return false;
+    WinoChain g;
+    g.K = p.input_channels;
+    g.N = batch;
+    g.OH = g.AH = p.input_h;
+    g.OW = g.AW = p.input_w;
+    g.TX = g.TX2 = pl.tiles_x;
+    g.T = g.T2 = pl.tiles_per_image;
+    g.Pp = g.Pp2 = pl.columns_padded;
+    g.Lm = g.Lv2 = wino_layout(g.K, g.Pp2, pl.column_block);
+    const long long planes = (long long)batch * g.K;
+    if (planes > 0x7fffffffLL) return false;
+    g.planes = (int)planes;
+    g.LDH = 6 * pl.tiles_y + 2;
+    g.LDW = 6 * pl.tiles_x + 4;
+    const size_t plane_bytes = (size_t)g.LDH * g.LDW * sizeof(float);
+    if (plane_bytes > 48 * 1024 || g.T2 > 512) return false;
+    int ppb = std::max(1, 256 / g.T2);
+    ppb = (int)std::min<size_t>(ppb, (48 * 1024) / plane_bytes);
+    const unsigned threads = std::max(256u, (unsigned)(g.T2 + 63) / 64 * 64);
+    // at most 7 vectors per lane and unit: the 8th costs the registers 3 waves per SIMD have (spill reloads are vmcnt-ordered behind the prefetch)
+    while (ppb > 1 && ceil_div(ppb * (hw >> 2), (int)threads) > 7) --ppb;
+    g.ppb = (int)std::min<long long>(ppb, planes);
+    const int nv = ceil_div(g.ppb * (hw >> 2), (int)threads);
+    if (nv > 7) return false;
+    const size_t lds = plane_bytes * g.ppb;
+    const long long units = (planes + g.ppb - 1) / g.ppb;
+    const int bpc = std::max(1, std::min((int)((160 * 1024) / lds), 12 / (int)(threads / 64)));
+    const unsigned grid = ((unsigned)std::min<long long>(units, (long long)device_compute_units() * bpc) + 7u) & ~7u;
+#define FHIP_K2S(NV_) case NV_: hipLaunchKernelGGL((wino_input_staged_kernel<NV_>), dim3(grid), dim3(threads), lds, s, v, input, g, (int)units); break
+    switch (nv)
+    {
+        FHIP_K2S(1);
+        FHIP_K2S(2);
+        FHIP_K2S(3);
+        FHIP_K2S(4);
+        FHIP_K2S(5);
+        FHIP_K2S(6);
+        default: FHIP_K2S(7);
+    }
+#undef FHIP_K2S
+    return true;
+}
+
 int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, const float* input, hipStream_t s)
 {
     fhip_winograd_plan pl;
@@ -792,7 +940,7 @@ int winograd_input_transform(const fhip_conv_param& p, int batch, float* v, cons
     dim3 grid((unsigned)((work + 255) / 256));
     if (pl.frequency_points == 36)
         hipLaunchKernelGGL(wino43_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
-    else
+    else if (!winograd_input_staged(p, batch, pl, v, input, s))
         hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, s, v, input, q);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;

@@ -286,10 +286,17 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
     __syncthreads(); // ptab ready
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) pck[j] = ptab[j * 256 + tid];
-    auto fetch_patch = [&](long long tt) {
-        const int tx_t = (int)(tt % q.tiles_x);
-        const long long t2 = tt / q.tiles_x;
-        const int ty_t = (int)(t2 % q.tiles_y), n = (int)(t2 / q.tiles_y);
+    // tile index -> (image, tile row, tile column) in 32-bit arithmetic, once per tile (the tile just decoded for the prefetch is the next
+    // iteration's current tile).  The six 64-bit divisions per tile this replaces (~120 mostly scalar instructions each) were hidden behind
+    // the other waves: MobileNet-V1 / ResNet-50 unchanged within 0.2 % (round 4)
+    const int ntiles = (int)q.tiles; // host: < 2^31
+    int nx_n = 0, nx_ty = 0, nx_tx = 0;
+    auto fetch_patch = [&](int tt) {
+        const int t2 = tt / q.tiles_x;
+        nx_tx = tt - t2 * q.tiles_x;
+        nx_n = t2 / q.tiles_y;
+        nx_ty = t2 - nx_n * q.tiles_y;
+        const int tx_t = nx_tx, ty_t = nx_ty, n = nx_n;
         const int iy0 = ty_t * TH * q.S - q.PT, ix0 = tx_t * TW * q.S - q.PL;
         const float* img = q.in + (size_t)n * q.C * HW;
         pok = 0;
@@ -303,13 +310,11 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
             pv[j] = img[(size_t)c * HW + (size_t)cy * q.W + cx];
         }
     };
-    if (blockIdx.x < q.tiles) fetch_patch(blockIdx.x);
+    if ((int)blockIdx.x < ntiles) fetch_patch((int)blockIdx.x);
 
-    for (long long t = blockIdx.x; t < q.tiles; t += gridDim.x)
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x)
     {
-        const int tx_t = (int)(t % q.tiles_x);
-        const long long t2 = t / q.tiles_x;
-        const int ty_t = (int)(t2 % q.tiles_y), n = (int)(t2 / q.tiles_y);
+        const int tx_t = nx_tx, ty_t = nx_ty, n = nx_n; // decoded by the fetch_patch that requested this tile
         const int oy0 = ty_t * TH, ox0 = tx_t * TW;
         __syncthreads(); // every wave is done reading the previous patch
 #pragma unroll
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
         __syncthreads();
         // the NEXT tile's patch is requested now, ahead of this tile's MFMAs and output stores: vmcnt retires in order and counts
         // stores, so loads issued behind the stores would wait for the stores to drain (measured: the whole gain of this kernel)
-        fetch_patch(min(t + (long long)gridDim.x, q.tiles - 1));
+        fetch_patch(min(t + (int)gridDim.x, ntiles - 1));
 
         f32x16 acc[TM];
 #pragma unroll
@@ -452,6 +457,7 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     q.tiles_x = ceil_div(q.OW, tw);
     q.tiles_y = ceil_div(q.OH, th);
     q.tiles = (long long)batch * q.tiles_x * q.tiles_y;
+    if (q.tiles > 0x7fffffffLL) return fail(FHIP_E_BADARG, "small-C convolution: more than 2^31 output tiles");
     q.has_bias = p.bias_term != 0;
     q.relu = relu;
     const int tm = q.K <= 32 ? 1 : 2, bm = 32 * tm;

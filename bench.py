@@ -224,7 +224,7 @@ def roofline_hbm(kernel, nbytes, ms, note):
 # kernels behind each roofline row, as rocprofv3 names them (profiles/<round>_<net>/traffic.json keys)
 TRAFFIC_KERNELS = {"Winograd tile GEMM": ("wino_gemm_glds", "WinoGemmPolicy"), "1x1 implicit GEMM": ("ConvGemmPolicy<1", "ConvGemmPolicy<2", "ConvGemmPolicy<5", "stream_gemm_kernel"),
                    "depthwise": ("depthwise3x3_",), "fused depthwise 3x3 + 1x1": ("ConvGemmPolicy<3", "ConvGemmPolicy<4", "dwpw_band_kernel"),
-                   "wino_input_transform_kernel": ("wino_input_transform_kernel", "wino43_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
+                   "wino_input_": ("wino_input_staged_kernel", "wino_input_transform_kernel", "wino43_input_transform_kernel", "wino_input_from_first"), "wino_chain_kernel": ("wino_chain_kernel",)}
 
 
 def _round_of(path):
@@ -434,8 +434,10 @@ def attribute(net, reps):
         roofs.append(roofline_mfma("fused depthwise 3x3 + 1x1 (the same launches, matrix side)", fz_flops, fz_ms, "2*K*C*Ho*Wo*N of the pointwise "
                                    "halves / the same durations"))
     if (k2_bytes or first_bytes) and stage.get("wino_input"):
-        roofs.append(roofline_hbm("wino_input_transform_kernel / wino_input_from_first_staged_kernel (first layer computed inside it: vector-ALU bound, "
-                                  "1728 FMAs per 64 V values)" if first_bytes else "wino_input_transform_kernel", k2_bytes + first_bytes, stage["wino_input"],
+        roofs.append(roofline_hbm("wino_input_from_first_staged_kernel (first layer computed inside the input transform: vector-ALU bound, "
+                                  "1296 FMAs per 64 V values)" if first_bytes else
+                                  "wino_input_staged_kernel (planes staged through LDS) / wino_input_transform_kernel / wino43_input_transform_kernel",
+                                  k2_bytes + first_bytes, stage["wino_input"],
                                   "4*(C*H*W + 64*C*T)*N summed over the Winograd layers that run an input transform (for the fused first layer: the "
                                   "image + the consumer's V) / sum of the input-transform HIP-event durations"))
     if chain_bytes and stage.get("wino_chain"):

@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __rest
 namespace fhip
 {
 
-// (An LDS-staged form of K2 -- coalesced 16-byte row loads into LDS, patches read from LDS -- was built and measured
-// SLOWER than this direct form on every VGG layer (1.37 ms vs 0.87 ms per step): the staging pass, its index
-// arithmetic and the extra barrier cost more than the uncoalesced 8-float patch loads, which the L1/L2 absorb.)
+// (Round 1 measured a one-shot LDS-staged K2 -- row loads into LDS, a barrier, windows from LDS -- slower than the direct form above on
+// VGG-16's planes (1.37 vs 0.87 ms per step).  Round 4's wino_input_staged_kernel below is the form that wins, on ResNet-50's 56 / 28 / 14-px
+// planes: whole planes as 16-byte vectors, persistent blocks, the next unit's vectors in flight while this one's windows are transformed.)
 struct WinoStaged
 {
     int UB;    // units per block

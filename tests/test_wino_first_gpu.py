@@ -48,7 +48,10 @@ CASES = [
     ("tiny", 2, 3, 3, 4, 3, True, True, False),
     ("wide_rows_direct_form", 1, 4, 14, 1200, 6, True, True, False),  # 4 x 22 x 1210 floats do not fit the LDS: the L1 form
     ("small_plane_direct_form", 2, 3, 40, 14, 18, True, True, False),  # 21 tiles per image: lanes run across images (direct form)
-    ("two_blocks_per_image", 3, 3, 64, 64, 24, True, True, False),  # 121 tiles: blocks of 64 + 57 tiles, 6 - 7 tile rows each, 2 channel groups
+    ("two_blocks_per_image", 3, 3, 64, 64, 24, True, True, False),  # 121 tiles: blocks of 63 + 58 tiles (shared columns), 2 channel groups
+    ("row_end_inside_image", 2, 3, 48, 48, 20, True, True, False),  # W = 6 TX: the row-end tile's column 6 is image column 47 -- staged form WITHOUT shared columns
+    ("unshared_w42", 2, 3, 40, 42, 9, True, True, False),  # W = 6 TX again (TX = 7, 49 tiles in one block)
+    ("shared_63_tiles_exact", 1, 3, 54, 50, 5, True, False, False),  # TX = 9, TY = 9: 81 tiles = 63 + 18; tile 63 starts a tile row (the helper copies tile 62)
 ]
 
 

@@ -279,51 +279,53 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
     const int poff = (pix >> q.tw_shift) * q.S * q.PW + (pix & (TW - 1)) * q.S;
     const size_t HW = (size_t)q.H * q.W;
 
-    // patch of tile `tt` -> registers: every load is issued unconditionally (clamped address), zeros are selected later
-    float pv[PASSES];
-    unsigned pok = 0;
+    // patch of tile `tt` -> registers: every load is issued unconditionally (clamped address), zeros are selected later.  TWO tiles are kept
+    // in flight per block where the registers allow (sets A and B, TM == 1: up to 32 output channels; round 4): with one, a block's tile took
+    // as long as an HBM round trip under load (MobileNet-V1 conv1 b256: 4 blocks per CU x 1 tile each = 1.25 us per tile and CU, 140 of the
+    // kernel's 174 us, the matrix pipe 23 % busy): MobileNet-V1 b256 69 820 -> 70 503 img/s.  With 64 output channels (TM == 2, ResNet-50's 7 x 7
+    // conv1: 144 -> 184 registers, 3 -> 2 blocks per CU) the second set loses 0.6 % of ResNet-50 b64: one set there.
+    constexpr int DEPTH = TM == 1 ? 2 : 1;
+    struct Pre
+    {
+        float pv[PASSES];
+        unsigned pok;
+        int n, ty, tx; // tile index -> (image, tile row, tile column), decoded once, in 32-bit arithmetic (host: tiles < 2^31)
+    };
     int pck[PASSES];
     __syncthreads(); // ptab ready
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) pck[j] = ptab[j * 256 + tid];
-    // tile index -> (image, tile row, tile column) in 32-bit arithmetic, once per tile (the tile just decoded for the prefetch is the next
-    // iteration's current tile).  The six 64-bit divisions per tile this replaces (~120 mostly scalar instructions each) were hidden behind
-    // the other waves: MobileNet-V1 / ResNet-50 unchanged within 0.2 % (round 4)
-    const int ntiles = (int)q.tiles; // host: < 2^31
-    int nx_n = 0, nx_ty = 0, nx_tx = 0;
-    auto fetch_patch = [&](int tt) {
+    const int ntiles = (int)q.tiles, G = (int)gridDim.x;
+    auto fetch_patch = [&](Pre& P, int tt) __attribute__((always_inline)) {
         const int t2 = tt / q.tiles_x;
-        nx_tx = tt - t2 * q.tiles_x;
-        nx_n = t2 / q.tiles_y;
-        nx_ty = t2 - nx_n * q.tiles_y;
-        const int tx_t = nx_tx, ty_t = nx_ty, n = nx_n;
-        const int iy0 = ty_t * TH * q.S - q.PT, ix0 = tx_t * TW * q.S - q.PL;
-        const float* img = q.in + (size_t)n * q.C * HW;
-        pok = 0;
+        P.tx = tt - t2 * q.tiles_x;
+        P.n = t2 / q.tiles_y;
+        P.ty = t2 - P.n * q.tiles_y;
+        const int iy0 = P.ty * TH * q.S - q.PT, ix0 = P.tx * TW * q.S - q.PL;
+        const float* img = q.in + (size_t)P.n * q.C * HW;
+        P.pok = 0;
 #pragma unroll
         for (int j = 0; j < PASSES; ++j)
         {
             const int c = pck[j] >> 16, r = (pck[j] >> 8) & 0xff, x = pck[j] & 0xff;
             const int iy = iy0 + r, ix = ix0 + x;
-            pok |= ((unsigned)iy < (unsigned)q.H && (unsigned)ix < (unsigned)q.W) ? (1u << j) : 0u;
+            P.pok |= ((unsigned)iy < (unsigned)q.H && (unsigned)ix < (unsigned)q.W) ? (1u << j) : 0u;
             const int cy = min(max(iy, 0), q.H - 1), cx = min(max(ix, 0), q.W - 1);
-            pv[j] = img[(size_t)c * HW + (size_t)cy * q.W + cx];
+            P.pv[j] = img[(size_t)c * HW + (size_t)cy * q.W + cx];
         }
     };
-    if ((int)blockIdx.x < ntiles) fetch_patch((int)blockIdx.x);
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x)
-    {
-        const int tx_t = nx_tx, ty_t = nx_ty, n = nx_n; // decoded by the fetch_patch that requested this tile
+    auto do_tile = [&](Pre& P, int t) __attribute__((always_inline)) {
+        const int tx_t = P.tx, ty_t = P.ty, n = P.n;
         const int oy0 = ty_t * TH, ox0 = tx_t * TW;
         __syncthreads(); // every wave is done reading the previous patch
 #pragma unroll
         for (int j = 0; j < PASSES; ++j)
-            if (j * 256 + tid < q.patch) patch[j * 256 + tid] = (pok & (1u << j)) ? pv[j] : 0.f;
+            if (j * 256 + tid < q.patch) patch[j * 256 + tid] = (P.pok & (1u << j)) ? P.pv[j] : 0.f;
         __syncthreads();
-        // the NEXT tile's patch is requested now, ahead of this tile's MFMAs and output stores: vmcnt retires in order and counts
-        // stores, so loads issued behind the stores would wait for the stores to drain (measured: the whole gain of this kernel)
-        fetch_patch(min(t + (int)gridDim.x, ntiles - 1));
+        // this register set's next tile (two ahead) is requested now, ahead of this tile's MFMAs and output stores: vmcnt retires in order and
+        // counts stores, so loads issued behind the stores would wait for the stores to drain
+        fetch_patch(P, min(t + DEPTH * G, ntiles - 1));
 
         f32x16 acc[TM];
 #pragma unroll
@@ -401,6 +403,19 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
                 }
             }
         }
+    };
+
+    Pre A, B;
+    const int t0 = (int)blockIdx.x;
+    if (t0 < ntiles)
+    {
+        fetch_patch(A, t0);
+        if (DEPTH == 2) fetch_patch(B, min(t0 + G, ntiles - 1));
+    }
+    for (int t = t0; t < ntiles; t += DEPTH * G)
+    {
+        do_tile(A, t);
+        if (DEPTH == 2 && t + G < ntiles) do_tile(B, t + G);
     }
 }
 

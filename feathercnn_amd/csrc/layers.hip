@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(float* __restrict__ y
     if (lane == 0) y[plane] = AVG ? v / HW : v;
 }
 
-// global pooling of SMALL planes (HW <= 128; the 7 x 7 planes in front of every classifier): the wave-per-plane form above spends a whole
+// global pooling of SMALL planes (HW < 128; the 7 x 7 planes in front of every classifier): the wave-per-plane form above spends a whole
 // wave, one 4-byte load per lane and a six-step butterfly on 49 values (MobileNet-V1 b256: 262 144 planes, 34 us for 51 MB).  Here a block copies
 // 128 consecutive planes -- one contiguous, 16-byte aligned run of the tensor -- to LDS with coalesced float4 loads (plane stride HW | 1: odd,
 // conflict-free) and lane t sums plane t in index order, the order of the reference's loop (layers/pooling_layer.h:60-75).
@@ -379,7 +379,7 @@ int fhip_pooling(const fhip_pool_param* p, int batch, float* y, const float* x, 
     {
         const int planes = q.planes;
         const int hw = q.H * q.W;
-        if (hw <= 128 && ((uintptr_t)x & 15) == 0)
+        if (hw < 128 && ((uintptr_t)x & 15) == 0) // 128 planes x (hw | 1) floats stay within the 64 KB a launch gets without asking
         {
             const dim3 grid(ceil_div(planes, kPlaneReducePB));
             const size_t lds = (size_t)kPlaneReducePB * (hw | 1) * sizeof(float);

@@ -56,7 +56,7 @@ POOLS = [  # (c, h, w, kernel, stride, (pl, pr, pt, pb), type, global)
     (2, 5, 9, 1, 1, (0, 0, 0, 0), 0, True), (2, 6, 6, 2, 2, (1, 0, 0, 1), 1, False),
     (3, 12, 12, 3, 2, (0, 0, 0, 0), 0, False), (2, 13, 16, 3, 2, (0, 0, 0, 0), 0, False), (2, 7, 4, 3, 2, (0, 0, 0, 0), 0, False),   # 3x3/s2 fast path
     (2, 9, 20, 3, 2, (0, 0, 0, 0), 0, False), (2, 3, 8, 3, 2, (0, 0, 0, 0), 0, False), (2, 15, 15, 3, 2, (0, 0, 0, 0), 0, False),
-    (200, 8, 8, 8, 1, (0, 0, 0, 0), 1, True), (131, 7, 7, 7, 1, (0, 0, 0, 0), 0, True), (3, 14, 14, 14, 1, (0, 0, 0, 0), 1, True)]  # global pooling: small-plane blocks of 128 (even / odd HW, ragged last block), wave-per-plane form above 128 pixels
+    (200, 8, 8, 8, 1, (0, 0, 0, 0), 1, True), (131, 7, 7, 7, 1, (0, 0, 0, 0), 0, True), (3, 14, 14, 14, 1, (0, 0, 0, 0), 1, True), (130, 9, 14, (9, 14), 1, (0, 0, 0, 0), 1, True), (5, 8, 16, (8, 16), 1, (0, 0, 0, 0), 0, True)]  # global pooling: small-plane blocks of 128 (even / odd HW, ragged last block), wave-per-plane form above 128 pixels
 
 
 @pytest.mark.parametrize("case", POOLS)

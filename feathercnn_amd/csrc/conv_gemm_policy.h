@@ -36,6 +36,13 @@ struct ConvGemmParams
     // agent-scope fences, and every such fence writes back the whole L2.)
     int split_k;
     float* partial;
+    // tail split (round 4; implicit_gemm.hip: igemm_tail): tiles % CUs column tiles at the end of an UNSPLIT launch would run as a last, nearly
+    // empty round of lone blocks (ResNet-50's 256 -> 1024 @14^2 b64: 1568 tiles = 6.125 per CU, the CUs that draw a seventh finish 13 us after
+    // the others).  Those column tiles [tail_nt0, n_tiles) are cut into split_k pieces along the reduction, which land one (or less) per CU;
+    // tail_main > 0 = number of unsplit blocks, and the grid is tail_main + pieces (both multiples of 8: decode() keeps an XCD's pieces behind
+    // ITS main blocks in dispatch order).  Pieces write partial[s][K][part_ntot] at column n - part_col0; the reduce kernel finishes them.
+    int tail_main, tail_nt0;
+    int part_ntot, part_col0; // row pitch / first column of `partial` (plain split-K: Ntot, 0)
     // optional residual (same layout as out), added before the activation: out = act(conv + bias + residual);
     // carried as a byte offset from `out` so the store path needs no second pointer table
     int has_residual;
@@ -92,9 +99,43 @@ struct ConvGemmPolicy
     }
 
     // bias of output row m for the prologue preload (split-K pieces store raw partial sums: no bias)
-    static __device__ float bias_at(const Params& p, int m) { return (p.has_bias && p.split_k <= 1 && m < p.K) ? p.bias[m] : 0.f; }
-    static __device__ int k_first(const Params& p, int split) { return (int)((long long)split * p.k_tiles / p.split_k); }
-    static __device__ int k_count(const Params& p, int split) { return k_first(p, split + 1) - k_first(p, split); }
+    // (tail split: the unsplit blocks carry split == split_k; the pieces' stores ignore the bias)
+    static __device__ float bias_at(const Params& p, int m) { return (p.has_bias && (p.split_k <= 1 || p.tail_main) && m < p.K) ? p.bias[m] : 0.f; }
+    static __device__ int k_cut(const Params& p, int split) { return (int)((long long)split * p.k_tiles / p.split_k); }
+    static __device__ int k_first(const Params& p, int split) { return (p.tail_main && split >= p.split_k) ? 0 : k_cut(p, split); }
+    static __device__ int k_count(const Params& p, int split)
+    {
+        return (p.tail_main && split >= p.split_k) ? p.k_tiles : k_cut(p, split + 1) - k_cut(p, split);
+    }
+    // block -> (row tile, column tile, split): the plain order of gemm_core.h, or the tail-split order
+    static __device__ void decode(const Params& p, int& mt, int& nt, int& split)
+    {
+        if (!p.tail_main)
+        {
+            int vid = xcd_remap(blockIdx.x, p.batches * p.m_tiles * p.n_tiles);
+            mt = vid % p.m_tiles;
+            vid /= p.m_tiles;
+            nt = vid % p.n_tiles;
+            split = vid / p.n_tiles;
+            return;
+        }
+        // XCD x = blockIdx % 8 runs its eighth of the main tiles, then its eighth of the pieces (the pieces of one tile next to each other)
+        const int x = blockIdx.x & 7, local = blockIdx.x >> 3, mp = p.tail_main >> 3, tp = ((int)gridDim.x - p.tail_main) >> 3;
+        if (local < mp)
+        {
+            const int id = x * mp + local;
+            mt = id % p.m_tiles;
+            nt = id / p.m_tiles;
+            split = p.split_k;
+        }
+        else
+        {
+            const int q = x * tp + (local - mp), tt = q / p.split_k;
+            split = q - tt * p.split_k;
+            mt = tt % p.m_tiles;
+            nt = p.tail_nt0 + tt / p.m_tiles;
+        }
+    }
 
     struct ALoad
     {
@@ -341,7 +382,7 @@ struct ConvGemmPolicy
         int first_new;             // MODE 5: first component of this slot group that no other group covers (0 but for an image's last group)
         __device__ Store(const Params& p, int split, int n4)
         {
-            part = p.split_k > 1 ? p.partial + (size_t)split * p.K * p.Ntot + n4 : nullptr;
+            part = (p.split_k > 1 && (!p.tail_main || split < p.split_k)) ? p.partial + (size_t)split * p.K * p.part_ntot + (n4 - p.part_col0) : nullptr;
             valid = 0;
             first_new = 0;
             if (MODE == 5)
@@ -397,8 +438,8 @@ struct ConvGemmPolicy
             if (m >= p.K) return;
             if (part)
             {
-                float* d = part + (size_t)m * p.Ntot;
-                if (valid == 0xfu && (p.Ntot & 3) == 0)
+                float* d = part + (size_t)m * p.part_ntot;
+                if (valid == 0xfu && (p.part_ntot & 3) == 0)
                     *reinterpret_cast<float4*>(d) = v;
                 else
                 {

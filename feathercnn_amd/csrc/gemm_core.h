@@ -34,6 +34,7 @@
 //     so consecutive virtual ids land on one XCD and walk m-tiles fastest: blocks that share a B panel / an A
 //     panel hit the same private 4 MiB L2 at the same time.
 #pragma once
+#include <type_traits>
 
 #include "common.h"
 
@@ -94,6 +95,15 @@ struct GemmShape
 // epilogues were measured and dropped: storing straight from the accumulators of an MFMA with swapped operand
 // roles (32-byte store pieces: -20 %) and batching the LDS transpose of a whole 32-column piece (block latency -3000 cycles,
 // throughput unchanged).
+template <class P, class = void>
+struct gemm_has_decode : std::false_type
+{
+};
+template <class P>
+struct gemm_has_decode<P, std::void_t<decltype(&P::decode)>> : std::true_type
+{
+};
+
 template <class Shape, class Policy>
 __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREADS / 256) void gemm_mfma_kernel(
     const typename Policy::Params prm)
@@ -106,12 +116,17 @@ __global__ __launch_bounds__(Shape::THREADS, Shape::BLOCKS_PER_CU* Shape::THREAD
     float* const Bs0 = lds + 2 * BK * BM; // Bs[buf] = Bs0 + buf * BK*BN
 
     __builtin_amdgcn_s_setprio(3);
-    const int nwg = prm.batches * prm.m_tiles * prm.n_tiles;
-    int vid = xcd_remap(blockIdx.x, nwg);
-    const int mt = vid % prm.m_tiles;
-    vid /= prm.m_tiles;
-    const int nt = vid % prm.n_tiles;
-    const int batch = vid / prm.n_tiles;
+    int mt, nt, batch;
+    if constexpr (gemm_has_decode<Policy>::value)
+        Policy::decode(prm, mt, nt, batch); // a policy with a block order of its own (ConvGemmPolicy: the tail split)
+    else
+    {
+        int vid = xcd_remap(blockIdx.x, prm.batches * prm.m_tiles * prm.n_tiles);
+        mt = vid % prm.m_tiles;
+        vid /= prm.m_tiles;
+        nt = vid % prm.n_tiles;
+        batch = vid / prm.n_tiles;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
     const int k_tiles = Policy::k_count(prm, batch); // tiles of THIS batch entry (a split-K piece may be uneven)
 

@@ -133,6 +133,37 @@ static int igemm_split(const fhip_conv_param& p, int batch)
     return std::max(want, 1);
 }
 
+// Tail split (conv_gemm_policy.h): for an UNSPLIT launch of the 128 x 64 tile whose tile count leaves a remainder of whole column tiles over the
+// CU count -- those last column tiles are cut `pieces` ways along the reduction so that the remainder lands as one short block per CU (or on a
+// part of the CUs) instead of a last round of lone full blocks.  Pure function of the geometry and the batch (GetBufferSize and Forward agree).
+// -> first tail column tile (0 = no tail split), *pieces.
+static int igemm_tail(const fhip_conv_param& p, int batch, int* pieces)
+{
+    *pieces = 1;
+#ifdef FHIP_NO_TAIL_SPLIT
+    return 0;
+#endif
+    if (p.group != 1 || p.kernel_h != 1 || p.kernel_w != 1 || p.pad_left || p.pad_right || p.pad_top || p.pad_bottom) return 0; // 1x1 routes only
+    if (stream_profitable(p, batch) || ip_profitable(p, batch) || igemm_split(p, batch) > 1) return 0; // (the small-C kernel takes K <= 64 only: excluded below)
+    if (conv_small_m(p.output_channels)) return 0;
+    const long long ntot = igemm_columns(p, batch);
+    if (conv_narrow_n((long long)batch * p.output_h * p.output_w)) return 0;
+    int kdp, kp;
+    igemm_packed_dims(p, &kdp, &kp);
+    const int m_tiles = kp / 128, n_tiles = (int)((ntot + 63) / 64), kt = kdp / kConvKTile, cus = device_compute_units();
+    const long long tiles = (long long)m_tiles * n_tiles;
+    // measured per layer (ResNet-50 b64 / MobileNet-V1 b256, tools/tail_layers.sh): 3.25 rounds 82 -> 76 us, 6.1 rounds 76 -> 73, 6.5 rounds 261 ->
+    // 248; at 12.25 rounds the pieces and their reduce launch cost what the shorter tail saves (+2 ... +3 us on 235 us): 8 rounds at most
+    if (tiles < cus || tiles > 8LL * cus || (cus & 7)) return 0;
+    const int rem = (int)(tiles % cus);
+    if (rem == 0 || rem % m_tiles || (m_tiles * (n_tiles - rem / m_tiles)) % 8) return 0;
+    int s = std::min(8, cus / rem);
+    while (s > 1 && (kt / s < 4 || (rem * s) % 8)) --s;
+    if (s < 2) return 0;
+    *pieces = s;
+    return n_tiles - rem / m_tiles;
+}
+
 bool igemm_streams(const fhip_conv_param& p, int batch) { return stream_profitable(p, batch); }
 
 size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
@@ -140,16 +171,24 @@ size_t igemm_buffer_bytes(const fhip_conv_param& p, int batch)
     if (ip_profitable(p, batch)) // [ xq: the re-packed activations | partial sums of the pieces ]
         return (ip_xq_floats(p) + (size_t)ip_pieces(p) * p.output_channels * batch) * sizeof(float);
     const int s = igemm_split(p, batch);
-    if (s <= 1) return 0;
+    if (s <= 1)
+    {
+        int pieces;
+        const int nt0 = igemm_tail(p, batch, &pieces);
+        if (!nt0) return 0;
+        const long long tail_cols = ((igemm_columns(p, batch) + 63) / 64 - nt0) * 64; // partial[pieces][K][tail columns]
+        return (size_t)pieces * p.output_channels * (size_t)tail_cols * sizeof(float);
+    }
     return (size_t)s * p.output_channels * (size_t)igemm_columns(p, batch) * sizeof(float);
 }
 
 // finishes a split-K convolution: out[img][m][rem] = act(sum_s partial[s][m][n] + bias[m])
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                                  const float* __restrict__ bias, const float* __restrict__ residual, int K,
-                                                                 int Ntot, int OHW, int S, int has_bias, int relu, int rag_gpi)
+                                                                 int Ntot, int OHW, int S, int has_bias, int relu, int rag_gpi, int col0, int pnt)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    // columns col0 .. Ntot - 1; partial is [S][K][pnt] with column n at n - col0 (plain split-K: col0 = 0, pnt = Ntot)
+    const int n = col0 + blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
     if (n >= Ntot) return;
     int img, rem;
@@ -167,8 +206,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(float* __restr
         img = n / OHW;
         rem = n - img * OHW;
     }
-    const size_t stride = (size_t)K * Ntot;
-    const float* src = partial + (size_t)m * Ntot + n;
+    const size_t stride = (size_t)K * pnt;
+    const float* src = partial + (size_t)m * pnt + (n - col0);
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += src[(size_t)s * stride];
     if (has_bias) v += bias[m];
@@ -522,8 +561,22 @@ static void launch(const ConvGemmParams& g0, hipStream_t s)
     g.m_tiles = g.Kp / Shape::BM;
     g.n_tiles = ceil_div(g.Ntot, Shape::BN);
     g.batches = g.split_k;
-    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE, TWIN>>), dim3(g.batches * g.m_tiles * g.n_tiles), dim3(Shape::THREADS), 0, s,
-                       g);
+    unsigned grid = (unsigned)(g.batches * g.m_tiles * g.n_tiles);
+    if (g.tail_nt0 > 0)
+    {
+        // tail split (igemm_tail): column tiles [0, tail_nt0) unsplit, the rest in split_k pieces each
+        g.tail_main = g.m_tiles * g.tail_nt0;
+        g.part_col0 = g.tail_nt0 * Shape::BN;
+        g.part_ntot = (g.n_tiles - g.tail_nt0) * Shape::BN;
+        grid = (unsigned)(g.tail_main + g.m_tiles * (g.n_tiles - g.tail_nt0) * g.split_k);
+    }
+    else
+    {
+        g.tail_main = 0;
+        g.part_col0 = 0;
+        g.part_ntot = g.Ntot;
+    }
+    hipLaunchKernelGGL((gemm_mfma_kernel<Shape, ConvGemmPolicy<MODE, TWIN>>), dim3(grid), dim3(Shape::THREADS), 0, s, g);
 }
 
 // force_no_act: the NAIVE algo ignores activation (avx/booster.cpp:41-61).
@@ -633,6 +686,13 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
         return FHIP_OK;
     }
     g.split_k = igemm_split(p, batch);
+    g.tail_main = g.tail_nt0 = 0;
+    if (g.split_k <= 1)
+    {
+        int pieces;
+        g.tail_nt0 = igemm_tail(p, batch, &pieces);
+        if (g.tail_nt0) g.split_k = pieces;
+    }
     if (g.split_k > 1 && !buffer) return fail(FHIP_E_BADARG, "this geometry runs split-K and needs the scratch buffer GetBufferSize asked for");
     g.partial = buffer;
     g.k_tiles = kdp / kConvKTile; // in total; a split reduces its share (ConvGemmPolicy::k_first / k_count)
@@ -675,8 +735,10 @@ int igemm_forward(const fhip_conv_param& p, int batch, float* out, const float* 
     FHIP_CHECK_HIP(hipGetLastError());
     if (g.split_k > 1)
     {
-        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot, 256), g.K), dim3(256), 0, s, out, g.partial, bias, residual, g.K,
-                           g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu, g.rag_gpi);
+        // (tail split: the columns from the first tail tile on; `partial` is [pieces][K][those columns, padded to whole tiles])
+        const int col0 = g.tail_nt0 * 64, pnt = g.tail_nt0 ? (ceil_div(g.Ntot, 64) - g.tail_nt0) * 64 : g.Ntot;
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(ceil_div(g.Ntot - col0, 256), g.K), dim3(256), 0, s, out, g.partial, bias, residual, g.K,
+                           g.Ntot, g.OHW, g.split_k, g.has_bias, g.relu, g.rag_gpi, col0, pnt);
         FHIP_CHECK_HIP(hipGetLastError());
     }
     return FHIP_OK;
@@ -753,6 +815,7 @@ int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int b
     g.relu2 = b.activation == FHIP_ACT_RELU;
     g.split_k = 1;
     g.partial = nullptr;
+    g.tail_main = g.tail_nt0 = 0;
     g.k_tiles = kdp / kConvKTile;
     g.m_tiles = 0;
     g.dw_w12 = g.dw_bias = nullptr;
@@ -862,6 +925,7 @@ int dwpw_forward(const fhip_conv_param& dw, const fhip_conv_param& pw, int batch
     g.has_bias = pw.bias_term != 0;
     g.relu = pw.activation == FHIP_ACT_RELU;
     g.split_k = 1;
+    g.tail_main = g.tail_nt0 = 0;
     g.k_tiles = kdp / kConvKTile;
     size_t w12 = 0;
     depthwise_packed_floats(dw, &w12);

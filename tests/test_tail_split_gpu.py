@@ -1,0 +1,83 @@
+"""Tail split of the 1x1 implicit GEMM (round 4; implicit_gemm.hip: igemm_tail, conv_gemm_policy.h): an unsplit launch of 128 x 64 tiles whose tile
+count leaves a remainder of whole column tiles over the CU count cuts those last column tiles along the reduction (pieces + the split-K reduce
+kernel on those columns only).  Checked through the C-ABI on the three operand modes it serves -- 16-byte columns (MODE 2), strided pixels
+(MODE 1), pixel slots (MODE 5) -- against the oracle, with NaN-filled scratch and twice (determinism), with the fused residual bit for bit against
+conv-then-add, and that neighbouring geometries keep the plain launch.  The geometries assume the MI355X's 256 CUs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import conv_geom, nerr, synth
+
+pytestmark = pytest.mark.gpu
+
+# (C, K, H, W, stride, batch): 260 / 328 / 260 tiles of 128 x 64 -> the last 2 / 18 / 2 column tiles in 2 pieces
+TAIL = [(128, 256, 26, 40, 1, 8), (128, 512, 52, 80, 2, 5), (160, 256, 7, 7, 1, 160)]
+# one full round exactly; a remainder that is not whole column tiles; too shallow to cut; more than 8 rounds
+PLAIN = [(128, 256, 32, 32, 1, 8), (128, 384, 26, 40, 1, 8), (64, 256, 26, 40, 1, 8), (128, 256, 52, 80, 1, 33)]
+
+
+def _layer(cuda, c, k, h, w, s, batch, act=1):
+    from feathercnn_amd import ConvLayer, ConvParam
+    from feathercnn_amd.booster import IM2COL
+    g = conv_geom(c, k, h, 1, s, 0, act=act, w=w)
+    x, wt, b = synth(g, batch, seed=c + k + s)
+    p = ConvParam(output_channels=k, input_channels=c, input_h=h, input_w=w, kernel_h=1, kernel_w=1, stride_h=s, stride_w=s, pad_left=0, pad_right=0,
+                  pad_top=0, pad_bottom=0, group=1, bias_term=True, activation=act, batch=batch)
+    return g, x, wt, b, p, ConvLayer(p, torch.from_numpy(wt).to(cuda), torch.from_numpy(b).to(cuda), algo=IM2COL)
+
+
+def _cus():
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+@pytest.mark.parametrize("c,k,h,w,s,batch", TAIL)
+def test_tail_columns_in_pieces_match_the_oracle(cuda, c, k, h, w, s, batch):
+    if _cus() != 256:
+        pytest.skip("geometries chosen for 256 CUs")
+    g, x, wt, b, p, layer = _layer(cuda, c, k, h, w, s, batch)
+    assert layer.buffer_bytes > 0, "the tail split needs scratch for its partial sums: this geometry should take it"
+    want = oracle.best().forward(g, x, wt, b)
+    scratch = torch.full((layer.buffer_bytes // 4,), float("nan"), device=cuda)
+    got = layer.Forward(torch.from_numpy(x).to(cuda), scratch=scratch).cpu().numpy()
+    assert got.shape == want.shape and nerr(got, want) <= 1e-5, (c, k, h, w, s, batch)
+    again = layer.Forward(torch.from_numpy(x).to(cuda)).cpu().numpy()
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("c,k,h,w,s,batch", PLAIN)
+def test_neighbouring_geometries_keep_the_plain_launch(cuda, c, k, h, w, s, batch):
+    if _cus() != 256:
+        pytest.skip("geometries chosen for 256 CUs")
+    g, x, wt, b, p, layer = _layer(cuda, c, k, h, w, s, batch)
+    assert layer.buffer_bytes == 0
+    if batch <= 8:
+        want = oracle.best().forward(g, x, wt, b)
+        got = layer.Forward(torch.from_numpy(x).to(cuda)).cpu().numpy()
+        assert nerr(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("c,k,h,w,s,batch", [TAIL[0], TAIL[2]])
+def test_tail_split_with_fused_residual(cuda, c, k, h, w, s, batch):
+    from feathercnn_amd import _lib
+    from feathercnn_amd.booster import IM2COL
+    if _cus() != 256:
+        pytest.skip("geometries chosen for 256 CUs")
+    lib = _lib.load_library()
+    g, x, wt, b, p0, plain = _layer(cuda, c, k, h, w, s, batch, act=0)
+    xt = torch.from_numpy(x).to(cuda)
+    y = plain.Forward(xt)
+    res = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, tuple(y.shape)).astype(np.float32)).to(cuda)
+    for act in (0, 1):
+        _, _, _, _, p, layer = _layer(cuda, c, k, h, w, s, batch, act=act)
+        cp = p._c()
+        out = torch.full_like(y, float("nan"))
+        scratch = torch.full((layer.buffer_bytes // 4,), float("nan"), device=cuda)
+        assert lib.fhip_conv_forward_residual(ctypes.byref(cp), IM2COL, batch, out.data_ptr(), xt.data_ptr(), layer.packed.data_ptr(), scratch.data_ptr(),
+                                              layer.bias.data_ptr(), res.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        want = y + res
+        assert torch.equal(out, torch.clamp_min(want, 0) if act else want), (c, k, h, w, s, batch, act)

@@ -272,6 +272,7 @@ struct SmallCParams
     int kd2;           // MFMA k-steps: ceil(Kd / 2) rounded up to a multiple of 4 (the extra rows meet zero weights)
     int PH, PW, patch; // patch rows, columns, floats
     int patch_alloc;   // LDS floats reserved for the patch (patch rounded up to 64)
+    int epi_alias;     // the epilogue's transpose buffer [4][16][36] lives in the patch area (which is at least that large)
     int tiles_x, tiles_y;
     long long tiles;
     int has_bias, relu;
@@ -288,14 +289,12 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
     float* const As = smem;                                        // [2*kd2][BM]
     float* const patch = As + (size_t)2 * q.kd2 * BM;              // [patch_alloc]
     int* const koff = reinterpret_cast<int*>(patch + q.patch_alloc); // [2][kd2]: koff[h*kd2 + kp] = patch offset of reduction row 2*kp + h
-    float* const scr = reinterpret_cast<float*>(koff + 2 * q.kd2) + 0; // [4][32][EPI_LD]
-    // the patch decode table (c << 16 | r << 8 | x per patch element) is read ONCE, before the tile loop: it lives in the epilogue's
-    // transpose buffer (PASSES * 256 <= 2816 ints of its 4608 floats; two barriers of the first tile separate the last read from the
-    // first epilogue write) -- 11 KB of LDS per block that buy a fourth / fifth resident block
-    int* const ptab = reinterpret_cast<int*>(scr);
-
+    // epilogue transpose buffer [4 waves][16 rows][EPI_LD] (two half passes per 32 x 32 accumulator).  Where the patch area is large enough it IS
+    // the patch area (q.epi_alias: ResNet-50's 7 x 7 conv1 -- 38.9 KB of weights + 9.5 KB of patch + 18.4 KB of transpose buffer were 67 KB = two
+    // blocks per CU; without the separate buffer three fit) at the price of one more barrier per tile: no wave may still be reading the patch
+    float* const scr = q.epi_alias ? patch : reinterpret_cast<float*>(koff + 2 * q.kd2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    // ---- once per block: weights, reduction-row table, patch decode table
+    // ---- once per block: weights, reduction-row table
     for (int i = tid; i < 2 * q.kd2 * (BM / 4); i += 256)
     {
         const int row = i / (BM / 4), c4 = i - row * (BM / 4);
@@ -306,12 +305,6 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
     {
         const int c = k / KHW, rem = k - c * KHW, u = rem / q.KW, w = rem - u * q.KW;
         koff[(k & 1) * q.kd2 + (k >> 1)] = k < q.Kd ? c * PHW + u * q.PW + w : 0; // padded rows multiply zero weights
-    }
-    for (int e = tid; e < kSmallCMaxPatch; e += 256)
-    {
-        const int ee = min(e, q.patch - 1);
-        const int c = ee / PHW, rem = ee - c * PHW, r = rem / q.PW, x = rem - r * q.PW;
-        ptab[e] = (c << 16) | (r << 8) | x;
     }
     const int pix = wave * 32 + l31;
     const int TW = 1 << q.tw_shift, TH = 128 >> q.tw_shift;
@@ -330,10 +323,15 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
         unsigned pok;
         int n, ty, tx; // tile index -> (image, tile row, tile column), decoded once, in 32-bit arithmetic (host: tiles < 2^31)
     };
-    int pck[PASSES];
-    __syncthreads(); // ptab ready
+    int pck[PASSES]; // the lane's patch elements, decoded once: c << 16 | row << 8 | column
 #pragma unroll
-    for (int j = 0; j < PASSES; ++j) pck[j] = ptab[j * 256 + tid];
+    for (int j = 0; j < PASSES; ++j)
+    {
+        const int ee = min(j * 256 + tid, q.patch - 1);
+        const int c = ee / PHW, rem = ee - c * PHW, r = rem / q.PW, x = rem - r * q.PW;
+        pck[j] = (c << 16) | (r << 8) | x;
+    }
+    __syncthreads(); // weights and the reduction-row table are in place
     const int ntiles = (int)q.tiles, G = (int)gridDim.x;
     auto fetch_patch = [&](Pre& P, int tt) __attribute__((always_inline)) {
         const int t2 = tt / q.tiles_x;
@@ -398,19 +396,22 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
             ko = kn;
         }
 
-        // ---- epilogue: per-wave LDS transpose, bias + ReLU, 16-byte stores of 4 consecutive pixels of one output row
-        float* const ws = scr + wave * (32 * EPI_LD);
+        // ---- epilogue: per-wave LDS transpose (16 rows at a time: registers 8 h .. 8 h + 7 of the C/D layout are rows 16 h .. 16 h + 15), bias +
+        // ReLU, 16-byte stores of 4 consecutive pixels of one output row
+        if (q.epi_alias) __syncthreads(); // the transpose buffer is the patch: every wave has left its k-loop
+        float* const ws = scr + wave * (16 * EPI_LD);
         const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
         const int p4 = wave * 32 + e_c4, oy = oy0 + (p4 >> q.tw_shift), ox = ox0 + (p4 & (TW - 1));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ih = 0; ih < 2 * TM; ++ih)
         {
+            const int i = ih >> 1, h = ih & 1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[i][r];
+            for (int r8 = 0; r8 < 8; ++r8) ws[((r8 & 3) + 8 * (r8 >> 2) + 4 * half) * EPI_LD + l31] = acc[i][8 * h + r8];
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
+            for (int qd = 0; qd < 2; ++qd)
             {
-                const int m = i * 32 + qd * 8 + e_row;
+                const int m = i * 32 + h * 16 + qd * 8 + e_row;
                 float4 v = *reinterpret_cast<const float4*>(&ws[(qd * 8 + e_row) * EPI_LD + e_c4]);
                 if (m < q.K && oy < q.OH && ox < q.OW)
                 {
@@ -516,7 +517,18 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     q.relu = relu;
     const int tm = q.K <= 32 ? 1 : 2, bm = 32 * tm;
     q.patch_alloc = round_up(q.patch, 64);
-    const size_t lds = ((size_t)2 * q.kd2 * bm + q.patch_alloc + 4 * 32 * 36) * sizeof(float) + ((size_t)2 * q.kd2) * sizeof(int);
+    // the transpose buffer of the epilogue (4 waves x 16 rows x 36 floats = 9 KB): a region of its own, or -- where that costs a resident block and
+    // the patch area is large enough (ResNet-50's 7 x 7 conv1: 38.9 KB of weights, 9.5 KB of patch) -- the patch area itself
+    const size_t lds_base = ((size_t)2 * q.kd2 * bm + q.patch_alloc) * sizeof(float) + ((size_t)2 * q.kd2) * sizeof(int);
+    const size_t scr_bytes = (size_t)4 * 16 * 36 * sizeof(float);
+    const int cap = q.S == 1 ? 6 : 4;
+    auto resident = [&](size_t bytes) { return (int)std::min<size_t>(cap, (size_t)(160 * 1024) / (bytes + 512)); };
+#ifdef FHIP_SMALLC_NO_ALIAS
+    q.epi_alias = 0;
+#else
+    q.epi_alias = (size_t)q.patch_alloc * sizeof(float) >= scr_bytes && resident(lds_base) > resident(lds_base + scr_bytes);
+#endif
+    const size_t lds = lds_base + (q.epi_alias ? 0 : scr_bytes);
     // resident blocks per CU (the grid is persistent): as many as the LDS takes, up to 6 at stride 1 and 4 at stride 2 (tools/conv1_bench.py,
     // same box: VGG conv1_1 b32 137 / 126 / 119 / 118 us with 3 / 4 / 5 / 6, MobileNet conv1 b256 191 / 183 / 191 / 191; an XCD-contiguous
     // tile order changed nothing)

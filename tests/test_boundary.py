@@ -138,6 +138,12 @@ def test_buffer_sizes_are_pure_and_scale_with_batch(lib):
     small = _param(conv_geom(512, 512, 7, 3, 1, 1), 64)
     sk = b.GetBufferSize(small)[0]
     assert sk > 0 and sk % (512 * 64 * 49 * 4) == 0 and sk // (512 * 64 * 49 * 4) in (2, 3, 4, 6, 8)
+    # round 4, tail split: an unsplit 1x1 launch of 1 .. 8 rounds of 128 x 64 tiles whose remainder over the 256 CUs is whole column tiles cuts
+    # those column tiles along the reduction: partial[pieces][K][tail columns] (ResNet-50 b64: res5 2c = 832 tiles, res4 2c = 1568; the
+    # 12.25 rounds of res3 2c are left alone)
+    assert b.GetBufferSize(_param(conv_geom(512, 2048, 7, 1, 1, 0), 64))[0] == 4 * 2048 * 256 * 4
+    assert b.GetBufferSize(_param(conv_geom(256, 1024, 14, 1, 1, 0), 64))[0] == 4 * 1024 * 256 * 4
+    assert b.GetBufferSize(_param(conv_geom(128, 512, 28, 1, 1, 0), 64))[0] == 0
     d = _param(conv_geom(32, 32, 28, 3, 1, 1, group=32), 4)
     b.SelectAlgo(d)
     assert b.algo == DEPTHWISE and b.GetBufferSize(d) == (0, (32 * 9 + 32 * 12) * 4)  # dense copy + 12-stride copy for 16-byte tap loads

@@ -51,7 +51,8 @@ STEADY_STEPS = 200  # length of the cross-check region timed after the contract'
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE when launched by torch.distributed.run, "
+                    "else 1).  Started WITHOUT a launcher and N > 1, bench.py starts the N ranks itself (launch_ranks)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--net", default=None, choices=list(DEFAULT_BATCH), help="time ONLY this net (default: VGG-16 as the headline value, then ResNet-50 and MobileNet-V1 in the same process)")
@@ -182,7 +183,12 @@ def net_cpu_baseline(net_name, model, procs, budget=30.0):
                       + (f" (P = {r['skipped']} not run: time cap {r['budget_s']:.0f}s or aggregate already under half of the best)" if r["skipped"] else "")
                       + f"; {r['sweep_s']:.1f}s sweep + {r['load_s']:.1f}s load, {wall:.1f}s wall",
             "sweep": r["sweep"], "single_core_images_per_s": one["images_per_s"] if one else None, "cpu_model": r["cpu_model"],
-            "host_cores": r["host_cores"]}
+            "host_cores": r["host_cores"],
+            # SURVEY.md 8(d) names P = nproc; that point is kept here next to the best of the sweep
+            "nproc_images_per_s": (r.get("nproc_point") or {}).get("images_per_s"), "nproc_point": r.get("nproc_point"),
+            "why_best_is_not_nproc": "every process streams the whole model (VGG-16: 550 MB of weights, re-read per image at N = 1) and its own "
+                                     "Winograd scratch through a memory system shared by all cores of the two sockets: the aggregate peaks where "
+                                     "that saturates (the sweep shows where) and falls beyond it; hardware threads past the physical cores add nothing"}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -320,12 +326,14 @@ def attribute(net, reps):
     convs = net.conv_params()
     fused_pw = net.fused_pointwise()
     siblings = net.siblings()      # 1: this 1x1 layer's launch also computes the next layer, 2: that next layer (launches nothing)
+    residuals = net.residuals()    # 1: an Eltwise SUM operand (output-sized) is read and added in this layer's GEMM epilogue
     chains = net.chains(raw=True)  # 2 = the pair "first layer computed inside the next layer's input transform"
     chain_bytes = first_bytes = 0.0
     fz_flops = fz_bytes = fz_ms = 0.0
     by_type, table = {}, []
-    gemm_flops = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = pw_bound_ms = direct = 0.0
-    pw_rows = []
+    gemm_flops = gemm_flops_64 = k2_bytes = dw_bytes = dw_ms = pw_flops = pw_ms = pw_bound_ms = direct = 0.0
+    pw_hbm_bytes = pw_hbm_ms = 0.0
+    pw_rows, pw_hbm_rows = [], []
     for i, ((typ, nm, algo), ms) in enumerate(zip(info, per_layer)):
         key = typ + ("/" + algo if algo else "")
         by_type[key] = by_type.get(key, 0.0) + ms
@@ -367,6 +375,8 @@ def attribute(net, reps):
                     raise SystemExit("bench: fhip_winograd_f63_plan failed on a layer the net runs as Winograd")
                 tiles, nxi = pl_.tiles_per_image, pl_.frequency_points
                 gemm_flops += 2.0 * nxi * p.output_channels * p.input_channels * tiles * n
+                # SURVEY.md 8(d)'s literal formula (64 points on ceil(Ho/6) * ceil(Wo/6) tiles) next to the executed work
+                gemm_flops_64 += 2.0 * 64 * p.output_channels * p.input_channels * (-(-p.output_h // 6)) * (-(-p.output_w // 6)) * n
                 row["winograd"] = f"F({pl_.tile_outputs}x{pl_.tile_outputs},3x3), {nxi} frequency points, {tiles} tiles per image"
                 v_in, v_out = chains.get(i, (0, 0))
                 if not v_in:
@@ -385,6 +395,10 @@ def attribute(net, reps):
                 pw_flops += fl
                 pw_ms += ms
                 by = 4.0 * ((p.input_channels + p.output_channels) * p.output_h * p.output_w * n + p.input_channels * p.output_channels)
+                if residuals.get(i) == 1:
+                    # the fused residual operand: one more output-sized tensor this launch reads (fhip_conv_forward_residual)
+                    by += 4.0 * p.output_channels * p.output_h * p.output_w * n
+                    row["fused_residual"] = True
                 if siblings.get(i) == 2:
                     # computed by the launch of the layer before (fhip_conv_forward_siblings): its work joins that row, it has no time of its own
                     row["computed_with_previous_layer"] = True
@@ -395,24 +409,39 @@ def attribute(net, reps):
                     ms, row_ = prev["ms"], prev
                     pw_rows.pop()
                     pw_bound_ms -= prev.pop("_bound_ms")
+                    if prev.pop("_was_hbm"):
+                        pw_hbm_rows.pop()
+                        pw_hbm_bytes -= prev["_by0"]
+                        pw_hbm_ms -= prev["_ms0"]
+                    prev.pop("_by0", None)
+                    prev.pop("_ms0", None)
                 else:
                     row_ = row
                 row_["mfma_frac"] = round(fl / max(ms, 1e-9) / 1e9 / PEAK_MFMA_F32_TFLOPS, 4)
                 pw_rows.append(row_["mfma_frac"])
                 # the layer's own lower bound: its matrix work at the MFMA peak or its compulsory bytes (the pixels the stride keeps, the
-                # output, the weights; a fused residual operand is NOT counted) at the HBM peak, whichever is longer
+                # output, the weights and -- round 5 -- the fused residual operand) at the HBM peak, whichever is longer
                 t_mfma, t_hbm = fl / (PEAK_MFMA_F32_TFLOPS * 1e9), by / (PEAK_HBM_GBS * 1e6)
                 pw_bound_ms += max(t_mfma, t_hbm)
                 row_["bound"] = "hbm" if t_hbm > t_mfma else "mfma"
                 row_["bound_frac"] = round(max(t_mfma, t_hbm) / max(ms, 1e-9), 4)
+                row_["hbm_bytes"] = by
+                row_["frac_hbm"] = round(by / max(ms, 1e-9) / 1e6 / PEAK_HBM_GBS, 4)
+                if t_hbm > t_mfma:
+                    pw_hbm_rows.append(row_["frac_hbm"])
+                    pw_hbm_bytes += by
+                    pw_hbm_ms += ms
                 if siblings.get(i) == 1:
-                    row["_fl"], row["_by"], row["_bound_ms"] = fl, by, max(t_mfma, t_hbm)
+                    row["_fl"], row["_by"], row["_bound_ms"], row["_was_hbm"], row["_by0"], row["_ms0"] = fl, by, max(t_mfma, t_hbm), t_hbm > t_mfma, by, ms
         table.append(row)
     roofs = []
     if gemm_flops and stage.get("wino_gemm"):
-        roofs.append(roofline_mfma("Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", gemm_flops,
+        roofs.append(dict(roofline_mfma("Winograd tile GEMM: wino_gemm_glds_kernel (C >= 128, K > 64) / gemm_mfma_kernel<WinoGemmPolicy>", gemm_flops,
                                    stage["wino_gemm"], "algorithmic FLOPs 2*xi*K*C*T*N (xi = 64 frequency points, T = ceil(Ho/6)*ceil(Wo/6) tiles; 7- and 8-pixel planes: xi = 36, T = ceil(Ho/4)*ceil(Wo/4)) summed over the Winograd layers of a step / "
-                                   "sum of their tile-GEMM HIP-event durations on the launch stream"))
+                                   "sum of their tile-GEMM HIP-event durations on the launch stream"),
+                          frac_survey_8d_formula=round(gemm_flops_64 / stage["wino_gemm"] / 1e9 / PEAK_MFMA_F32_TFLOPS, 4),
+                          frac_survey_8d_note="the same durations against SURVEY.md 8(d)'s literal 2*64*K*C*ceil(Ho/6)*ceil(Wo/6)*N (layers that run "
+                          "F(4x4,3x3) execute 36 points on more tiles; `frac` counts the work executed)"))
     if pw_flops and pw_ms:
         r = roofline_mfma("1x1 implicit GEMM: gemm_mfma_kernel<ConvGemmPolicy<1|2|5>> (+ split-K reduce) / stream_gemm_kernel (C >= 256, 128 <= K <= 512)", pw_flops, pw_ms,
                           "ConvParam::GetFLOPS 2*K*C*Ho*Wo*N summed over the 1x1 convolution layers of a step / sum of their per-layer "
@@ -423,6 +452,11 @@ def attribute(net, reps):
         # sum of the layers' own lower bounds (max of MFMA time at 157.3 TF and HBM time at 8 TB/s, per layer) / measured time: what the
         # MFMA fraction alone understates for the layers that are bandwidth-bound at this batch (ResNet-50's 64 -> 256 @56x56)
         r["frac_of_tighter_bound"] = round(pw_bound_ms / pw_ms, 4)
+        if pw_hbm_rows:
+            # the layers whose compulsory bytes (fused residual operand included) take longer at 8 TB/s than their matrix work at 157.3 TF
+            r["hbm_bound_layers"] = {"layers": len(pw_hbm_rows), "ms_per_step": round(pw_hbm_ms, 4), "bytes_per_step": pw_hbm_bytes,
+                                     "frac_hbm": round(pw_hbm_bytes / pw_hbm_ms / 1e6 / PEAK_HBM_GBS, 4), "layer_frac_hbm_min": min(pw_hbm_rows)}
+            r["layer_frac_min_is"] = "mfma fraction of the slowest layer; hbm_bound_layers.layer_frac_hbm_min is the HBM fraction of the slowest HBM-bound layer"
         roofs.append(r)
     if dw_bytes and stage.get("depthwise"):
         roofs.append(roofline_hbm("depthwise: depthwise3x3_flat_kernel (7 / 14 / 28-pixel planes) / depthwise3x3_band_kernel (112 / 56 pixels, stride 1) / depthwise3x3_direct_kernel", dw_bytes, stage["depthwise"], "compulsory bytes 4*(C*Hin*Win + C*Ho*Wo)*N + 40*C "
@@ -490,9 +524,10 @@ def timed_region(step, steps, warmup, env):
     return dt
 
 
-def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail=True, steady=0):
+def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail=True, steady=0, model=None):
     """One benchmark network through the feather::Net runtime: build (rank 0) + one RCCL broadcast of the .bin, timed region,
-    per-kernel attribution.  -> result dict (rank 0 carries the detail)."""
+    per-kernel attribution.  -> result dict (rank 0 carries the detail).  `model` given: no broadcast (the caller already holds the
+    model -- the one-rank reference point that rank 0 times by itself inside an N > 1 run, env["world"] == 1 there)."""
     import numpy as np
     import torch
 
@@ -501,7 +536,10 @@ def measure_net(net_name, a, env, steps, warmup, global_batch=0, batch=0, detail
     from feathercnn_amd.shard import broadcast_model
     dev, rank, world = env["dev"], env["rank"], env["world"]
     nb = per_gpu_batch(net_name, a, env, global_batch, batch)
-    model, t_bcast, bcast_bytes = broadcast_model(model_zoo.MODELS[net_name], dev, src=0)
+    if model is None:
+        model, t_bcast, bcast_bytes = broadcast_model(model_zoo.MODELS[net_name], dev, src=0)
+    else:
+        t_bcast, bcast_bytes = 0.0, 0
     p, b, in_name, out_name = model
     replicas = a.sub_batches if a.sub_batches > 0 else SUB_BATCHES.get(net_name, 1)
     replicas = max(1, min(replicas, nb))
@@ -586,9 +624,19 @@ def shard_check(net_name, model, a, env):
         n_.close()
         return y
     lo, hi = shard_range(G, rank, world)
-    mine = run(x_all[lo:hi])
-    width = mine.shape[1]
     cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # gloo (the one-GPU rehearsal) gathers host tensors
+    mine, err_local = None, None
+    try:
+        mine = run(x_all[lo:hi])
+    except Exception as e:  # caught HERE, so that every rank still reaches the collectives below in the same order
+        err_local = repr(e)
+    # agree on success BEFORE any data collective: a rank that failed must not leave the others waiting in all_gather
+    flag = torch.tensor([0 if mine is None else mine.shape[1]], dtype=torch.int64, device=cdev)
+    lo_flag = flag.clone()
+    dist.all_reduce(lo_flag, op=dist.ReduceOp.MIN)
+    if int(lo_flag.item()) == 0:
+        return {"net": net_name, "ok": None, "error": err_local or "another rank failed its shard"} if rank == 0 else None
+    width = mine.shape[1]
     pad = torch.zeros((G // world + 1, width), dtype=torch.float32, device=cdev)
     pad[:hi - lo] = torch.from_numpy(mine).to(cdev)
     parts = [torch.empty_like(pad) for _ in range(world)]
@@ -731,12 +779,42 @@ def setup_convstack(a, env):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here -- this process becomes
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`,
+    one rank per GPU over RCCL, exactly the command the driver contract names -- and hand its exit status on.  Rank 0's JSON line goes to
+    this process's stdout unchanged.  Fails loudly when the node has fewer than N GPUs (FHIP_BENCH_SHARE_GPU=1: the one-GPU rehearsal,
+    every rank on cuda:0 over gloo; its numbers mean nothing)."""
+    import socket
+    import subprocess
+
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("FHIP_BENCH_SHARE_GPU") != "1" and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s); one rank per GPU is the only mode that measures anything "
+                         "(FHIP_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench: --gpus {n} without a launcher: starting {n} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus or 1) > 1:
+        raise SystemExit(launch_ranks(a.gpus))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus is not None and a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the flag and the run must agree")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -795,15 +873,19 @@ def main():
                                                               detail=False)
             else:
                 # configs[4]: ResNet-50, 512 images in total sharded over the ranks (strong), plus its weak point (64 per GPU)
-                extras["resnet50_global512"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, global_batch=512)
+                extras["resnet50_global512"], r50_model = measure_net("resnet50", a, env, a.steps, a.warmup, global_batch=512)
                 extras["resnet50"], _ = measure_net("resnet50", a, env, a.steps, a.warmup, detail=False)
+                # the ONE-GPU point of the same strong-scaling curve, in the same run: rank 0 alone runs all 512 images (no collective inside:
+                # its env says world = 1 and it already holds the model); the other ranks wait at the barrier below
+                if rank == 0:
+                    extras["resnet50_global512_one_gpu"], _ = measure_net("resnet50", a, dict(env, world=1), max(a.steps // 5, 5), max(a.warmup // 2, 1),
+                                                                          global_batch=512, detail=False, model=r50_model)
+                dist.barrier()
     shard_ok = None
     if world > 1:
         if a.mode == "net":
-            try:
-                shard_ok = shard_check(head_net, model, a, env)
-            except Exception as e:  # a cross-check must never take the measured line down with it (every rank takes this path together or not at all:
-                shard_ok = {"ok": None, "error": repr(e)}  # the collectives inside are the first and last thing the ranks do in it)
+            # errors of a rank's own run are caught inside and agreed on with an all_reduce before the gather (no mismatched collectives)
+            shard_ok = shard_check(head_net, model, a, env)
         dist.barrier()
 
     if rank == 0:
@@ -849,6 +931,56 @@ def main():
                 res["rooflines"][name] = e["rooflines"]
             tables[name] = e.get("table", [])
         res["nets"] = nets_out
+        # ---- compact per-net summary inside the two objects every consumer of this line keeps (`config`, `roofline`): the other metric nets
+        # ---- of BASELINE.json next to the headline, with the fraction of each one's hot kernels (full detail stays in nets / rooflines)
+        short = {"Winograd tile GEMM": "tile_gemm", "1x1 implicit GEMM": "gemm1x1", "depthwise:": "dw", "fused depthwise 3x3 + 1x1:": "dwpw_hbm",
+                 "fused depthwise 3x3 + 1x1 (": "dwpw_mfma", "wino_input_": "wino_input", "wino_chain_kernel": "wino_chain"}
+
+        def key_of(r):
+            return next((v for k, v in short.items() if r["kernel"].startswith(k)), r["kernel"][:24])
+
+        other, also = {}, {}
+        for name, e in nets_out.items():
+            tag = f"{name}_b{e['per_gpu_batch']}" if e.get("scaling") != "strong" else f"{name.split('_global')[0]}_g{e['global_batch']}" + ("_one_gpu" if name.endswith("_one_gpu") else "")
+            row = {"img_s": e["images_per_s"], "ms_per_step": e["ms_per_step"]}
+            if e.get("steady_state"):
+                row["img_s_steady"] = e["steady_state"]["images_per_s"]
+            for r in res["rooflines"].get(name, []):
+                k = key_of(r)
+                row[k + "_frac"] = r["frac"]
+                if k == "gemm1x1":
+                    row["gemm1x1_frac_of_tighter_bound"] = r.get("frac_of_tighter_bound")
+                    if r.get("hbm_bound_layers"):
+                        row["gemm1x1_hbm_bound_layers_frac_hbm"] = r["hbm_bound_layers"]["frac_hbm"]
+                if k == "tile_gemm" and "frac_survey_8d_formula" in r:
+                    row["tile_gemm_frac_8d_formula"] = r["frac_survey_8d_formula"]
+                also.setdefault(tag, []).append({"kernel": k, "bound": r["bound"], "frac": r["frac"], "achieved": r["achieved"], "unit": r["unit"],
+                                                 "ms_per_step": r["ms_per_step"]})
+            if name != head_net or e.get("scaling") == "strong":
+                other[tag] = row
+            else:
+                res["config"]["headline_net"] = dict(row, tag=tag)
+        # configs[4] (ResNet-50, 512 images in total over 8 GPUs, strong scaling): the number the curve will be judged against, written down
+        # BEFORE the 8-GPU node exists.  Definition: efficiency(n) = img/s(n GPUs, global batch 512) / (n x img/s(1 GPU, global batch 512)).
+        # At n = 8 every GPU runs 64 images per step, so -- the data path has no collective -- the expected per-GPU rate is the 1-GPU rate
+        # at batch 64, and the expected efficiency is img/s(b64) / img/s(b512) on one GPU.
+        g512 = nets_out.get("resnet50_global512_one_gpu") if world > 1 else nets_out.get("resnet50_global512")
+        b64 = nets_out.get("resnet50")
+        if g512 and b64 and b64.get("per_gpu_batch") == 64:
+            exp = {"definition": "strong-scaling efficiency at n GPUs = img/s(n GPUs, global batch 512) / (n x img/s(1 GPU, global batch 512))",
+                   "one_gpu_global512_img_s": g512["images_per_s"], "one_gpu_b64_img_s": b64["images_per_s"] / (world if b64.get("scaling") == "weak" else 1),
+                   "predicted_img_s_at_8_gpus": round(8 * b64["images_per_s"] / (world if b64.get("scaling") == "weak" else 1), 1),
+                   "predicted_efficiency_at_8_gpus": round(b64["images_per_s"] / (world if b64.get("scaling") == "weak" else 1) / g512["images_per_s"], 4),
+                   "per_gpu_b64_img_s_needed_for_0.9": round(0.9 * g512["images_per_s"], 1),
+                   "why_below_1": "a GPU at 64 images per step runs shorter launches (block turnover, tails) than at 512: the loss is on-chip, not in a collective"}
+            if world > 1 and "resnet50_global512" in nets_out:
+                exp["measured_img_s_at_this_n"] = nets_out["resnet50_global512"]["images_per_s"]
+                exp["measured_efficiency_at_this_n"] = round(nets_out["resnet50_global512"]["images_per_s"] / (world * g512["images_per_s"]), 4)
+            nets_out["resnet50_global512"]["expected_from_1gpu"] = exp
+            other.setdefault("resnet50_g512", {})["expected_from_1gpu"] = {k: exp[k] for k in exp if k not in ("definition", "why_below_1")}
+        res["config"]["other_nets"] = other
+        if res.get("roofline"):
+            res["roofline"] = dict(res["roofline"], also=also)
         if not a.no_cpu_baseline and world == 1:
             try:
                 if a.mode == "convstack":

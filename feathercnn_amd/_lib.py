@@ -105,6 +105,7 @@ SIGNATURES = {
     "fhip_net_layer_fused_pointwise": (_I, [_V, _I, _P, _PI]),
     "fhip_net_layer_chain": (_I, [_V, _I, _PI, _PI]),
     "fhip_net_layer_sibling": (_I, [_V, _I, _PI]),
+    "fhip_net_layer_residual": (_I, [_V, _I, _PI]),
     "fhip_net_forward_timed": (_I, [_V, ctypes.POINTER(ctypes.c_float)]),
     "fhip_net_memory": (_I, [_V, ctypes.POINTER(_SZ), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
 }

@@ -353,6 +353,7 @@ struct Layer
     virtual const fhip_conv_param* fused_pointwise(int*) const { return nullptr; } // the 1x1 convolution a depthwise layer absorbed
     virtual void chain_state(int* v_from_previous, int* writes_next_v) const { *v_from_previous = *writes_next_v = 0; }
     virtual int sibling_state() const { return 0; } // 1: launches the GEMM that also computes the NEXT layer; 2: computed by the layer before
+    virtual int residual_state() const { return 0; } // 1: an Eltwise SUM operand is added in this layer's GEMM epilogue; 2: absorbed, added by a separate launch
 };
 
 struct Net
@@ -728,6 +729,7 @@ struct ConvLayer : Layer
     const fhip_conv_param* conv_param() const override { return &p; }
     int algo() const override { return algo_; }
     int sibling_state() const override { return sib ? 1 : sib_of ? 2 : 0; }
+    int residual_state() const override { return !residual ? 0 : res_fast ? 1 : 2; }
     void chain_state(int* v_from_previous, int* writes_next_v) const override
     {
         *v_from_previous = head ? 2 : chain_in ? 1 : 0;
@@ -1962,6 +1964,14 @@ int fhip_net_layer_sibling(fhip_net* n, int index, int* state)
     NET_GUARD(n);
     if (index < 0 || index >= (int)n->impl.layers.size() || !state) return fail(FHIP_E_BADARG, "layer index out of range");
     *state = n->impl.layers[index]->sibling_state();
+    return FHIP_OK;
+}
+
+int fhip_net_layer_residual(fhip_net* n, int index, int* state)
+{
+    NET_GUARD(n);
+    if (index < 0 || index >= (int)n->impl.layers.size() || !state) return fail(FHIP_E_BADARG, "layer index out of range");
+    *state = n->impl.layers[index]->residual_state();
     return FHIP_OK;
 }
 

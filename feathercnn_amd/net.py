@@ -143,6 +143,16 @@ class Net:
                 out[i] = st.value
         return out
 
+    def residuals(self):
+        """{layer index: 1 | 2} -- 1: the absorbed Eltwise SUM operand is added in this convolution's GEMM epilogue (one more output-sized read by
+        the same launch, fhip_conv_forward_residual), 2: absorbed but added by a launch of its own (fhip_net_layer_residual)."""
+        out = {}
+        for i in range(self._lib.fhip_net_layer_count(self._h)):
+            st = ctypes.c_int()
+            if self._lib.fhip_net_layer_residual(self._h, i, ctypes.byref(st)) == 0 and st.value:
+                out[i] = st.value
+        return out
+
     def chains(self, raw=False):
         """{layer index: (v_from_previous, writes_next_v)} for the convolutions that are part of a chained Winograd run (fusion level 3).
         raw=True keeps the library's values: 2 marks the pair "first layer computed inside the next layer's input transform" -- (0, 2) on the

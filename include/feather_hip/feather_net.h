@@ -226,6 +226,10 @@ FHIP_API int fhip_net_layer_chain(fhip_net* net, int index, int* v_from_previous
 /* Fusion level 2: *state = 1 when this 1x1 convolution's launch also computes the NEXT layer of the list (a 1x1 convolution of the same
  * input: fhip_conv_forward_siblings), 2 when this layer is that next one (it launches nothing), 0 otherwise. */
 FHIP_API int fhip_net_layer_sibling(fhip_net* net, int index, int* state);
+/* Fusion level 2: *state = 1 when an Eltwise SUM behind this convolution was absorbed and its other operand is added in the GEMM epilogue
+ * (fhip_conv_forward_residual: the operand is one more read of an output-sized tensor by this launch), 2 when it was absorbed but is added by a
+ * launch of its own (fhip_add), 0 when the layer has no residual operand. */
+FHIP_API int fhip_net_layer_residual(fhip_net* net, int index, int* state);
 /* One eager forward with a pair of events around every layer; ms must hold layer_count entries. */
 FHIP_API int fhip_net_forward_timed(fhip_net* net, float* ms);
 /* Device bytes currently held: blobs, weights, scratch arena. */

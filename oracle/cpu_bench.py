@@ -122,6 +122,17 @@ def main():
             # past the knee: more processes only thrash the memory system (each forward streams the whole model and its activations)
             skipped += [q for q in plist if q > p]
             break
+    nproc_point = next((r for r in sweep if r["procs"] == ncpu), None)
+    if nproc_point is None and not os.environ.get("FHIP_CPU_BENCH_NO_NPROC"):
+        # SURVEY.md 8(d) names P = nproc: keep that figure in the line even when the sweep stopped before it (past the knee it is far from
+        # the best point).  One warm-up + ONE timed forward per worker: the deadline is already over when the workers start, and a worker
+        # never does fewer than one timed forward.
+        times, wall = run_procs(ref, cores, ncpu, 1, time.monotonic())
+        if len(times) == ncpu:
+            means = [sum(t) / len(t) for t in times]
+            nproc_point = {"procs": ncpu, "images_per_s": round(sum(1.0 / m for m in means), 3), "mean_forward_s": round(sum(means) / len(means), 4),
+                           "best_forward_s": round(min(min(t) for t in times), 4), "timed_forwards_per_worker": min(len(t) for t in times),
+                           "wall_s": round(wall, 2), "outside_sweep": True}
     ref.close()
     model = ""
     try:
@@ -132,7 +143,7 @@ def main():
     except OSError:
         pass
     best = max(sweep, key=lambda r: r["images_per_s"]) if sweep else None
-    json.dump({"sweep": sweep, "skipped": skipped, "best": best, "reps": reps, "warmup": 1, "host_cores": ncpu, "cpu_model": model,
+    json.dump({"sweep": sweep, "skipped": skipped, "best": best, "nproc_point": nproc_point, "reps": reps, "warmup": 1, "host_cores": ncpu, "cpu_model": model,
                "load_s": round(load_s, 2), "sweep_s": round(time.perf_counter() - t_start, 2), "budget_s": a.budget}, sys.stdout)
     sys.stdout.write("\n")
 

@@ -41,3 +41,36 @@ def test_bench_two_ranks_share_one_gpu(cuda):
     sc = r["shard_check"]
     assert sc["ok"] and sc["global_batch"] == 5 and sc["shares"] == [3, 2] and sc["max_norm_err"] <= 1e-5, sc
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks_itself(cuda):
+    """plain `python bench.py --gpus 2` -- no torch.distributed.run in front -- must start two ranks by itself (launch_ranks) and
+    print one JSON line with n_gpus == 2; the same one-GPU rehearsal switch.  Also: the compact per-net summary sits inside `config` and
+    `roofline` (the objects a consumer that trims unknown top-level keys still keeps), and config 5's expectation is written into the line."""
+    from feathercnn_amd import model_zoo
+    env = dict(os.environ, FHIP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-steady", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["shard_check"]["ok"] and r["weight_broadcast"]["bytes"] == len(model_zoo.MODELS["vgg16"]()[1])
+    other = r["config"]["other_nets"]
+    assert other["resnet50_g512"]["img_s"] > 0 and other["resnet50_b64"]["img_s"] > 0 and other["resnet50_g512_one_gpu"]["img_s"] > 0
+    exp = r["nets"]["resnet50_global512"]["expected_from_1gpu"]
+    assert exp["measured_efficiency_at_this_n"] > 0 and exp["predicted_efficiency_at_8_gpus"] > 0
+    assert r["roofline"]["also"]["vgg16_b32"][0]["kernel"] == "tile_gemm"
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_must_agree_with_the_launcher(cuda):
+    """--gpus 4 under a launcher that started 2 ranks: refused before anything is measured (the flag can never disagree with the run)."""
+    env = dict(os.environ, FHIP_BENCH_SHARE_GPU="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True, timeout=300,
+                         env=env, cwd=ROOT)
+    assert out.returncode != 0 and "must agree" in out.stderr

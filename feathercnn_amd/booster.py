@@ -244,15 +244,16 @@ def winograd_plan(param: ConvParam):
 
 
 def winograd_rows(buf, plan, rows: int):
-    """A Winograd scratch tensor (V: rows = input channels, M: rows = output channels) as [64 xi][rows][Pp], whatever its storage: the
-    library keeps V and M in blocks of plan.column_block columns, [Pp / BP][64][rows][BP] (include/feather_hip/feather_hip.h; BP == Pp is
-    the whole-row form).  Works on torch tensors and numpy arrays (flat, at least 64 * rows * Pp floats)."""
-    pp, bp = plan.columns_padded, plan.column_block
-    flat = buf.reshape(-1)[:64 * rows * pp]
+    """A Winograd scratch tensor (V: rows = input channels, M: rows = output channels) as [xi][rows][Pp], whatever its storage: the
+    library keeps V and M in blocks of plan.column_block columns, [Pp / BP][xi][rows][BP] (include/feather_hip/feather_hip.h; BP == Pp is
+    the whole-row form).  xi runs over plan.frequency_points: 64 for F(6x6,3x3), 36 on the planes that run F(4x4,3x3).  Works on torch
+    tensors and numpy arrays (flat, at least frequency_points * rows * Pp floats)."""
+    pp, bp, nxi = plan.columns_padded, plan.column_block, plan.frequency_points
+    flat = buf.reshape(-1)[:nxi * rows * pp]
     if bp >= pp:
-        return flat.reshape(64, rows, pp)
-    blocked = flat.reshape(pp // bp, 64, rows, bp)
-    return (blocked.permute(1, 2, 0, 3) if hasattr(blocked, "permute") else blocked.transpose(1, 2, 0, 3)).reshape(64, rows, pp)
+        return flat.reshape(nxi, rows, pp)
+    blocked = flat.reshape(pp // bp, nxi, rows, bp)
+    return (blocked.permute(1, 2, 0, 3) if hasattr(blocked, "permute") else blocked.transpose(1, 2, 0, 3)).reshape(nxi, rows, pp)
 
 
 def can_chain_winograd(a: "ConvLayer", b: "ConvLayer", pool: bool = False) -> bool:

@@ -54,6 +54,71 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 __device__ __forceinline__ float apply_act(float v, bool relu) { return relu ? fmaxf(v, 0.f) : v; }
 
+// 16-byte global accesses with the non-temporal hint (`nt`), for streams that pass through the cache hierarchy exactly once.
+__device__ __forceinline__ float4 ldg4_nt(const float* p)
+{
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg4_nt(float* p, float4 v)
+{
+    f32x4 w;
+    w.x = v.x;
+    w.y = v.y;
+    w.z = v.z;
+    w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+}
+// experiment forms of the same store: write-through (`sc1`: the line is dropped from the XCD's L2) with or without `nt`
+template <int MODE> // 4: sc1, 6: sc1 nt, 8: sc0 sc1
+__device__ __forceinline__ void stg4_asm(float* p, float4 v)
+{
+    f32x4 w;
+    w.x = v.x;
+    w.y = v.y;
+    w.z = v.z;
+    w.w = v.w;
+    if constexpr (MODE == 4)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    else if constexpr (MODE == 6)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(w) : "memory");
+    else
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+// 16-byte stores of ACTIVATIONS (layer outputs).  FHIP_ACT_NT is a mask of the kernel families whose output stores carry `nt`:
+// 1 = implicit-GEMM / streamed 1x1 convolutions, 2 = the staged Winograd output transform, 4 = depthwise kernels, 8 = the band-staged
+// depthwise + pointwise kernel (measured per build with tools/variant_ab.sh).
+#ifndef FHIP_ACT_NT
+#define FHIP_ACT_NT 0
+#endif
+template <int FAMILY>
+__device__ __forceinline__ void stg4_act(float* p, float4 v)
+{
+    if constexpr ((FHIP_ACT_NT & FAMILY) != 0)
+        stg4_nt(p, v);
+    else
+        *reinterpret_cast<float4*>(p) = v;
+}
+
+// Dword accesses of the Winograd transforms to the scratch tensors V / M.  Every element of V and M is written once by one launch and
+// read once by the next one: FHIP_XFORM_NT bit 0 puts the non-temporal hint on those loads, bit 1 on those stores (measured per build with
+// tools/variant_ab.sh; 0 = plain accesses).
+#ifndef FHIP_XFORM_NT
+#define FHIP_XFORM_NT 0
+#endif
+__device__ __forceinline__ float ld_scratch(const float* p)
+{
+    if constexpr ((FHIP_XFORM_NT & 1) != 0) return __builtin_nontemporal_load(p);
+    return *p;
+}
+__device__ __forceinline__ void st_scratch(float* p, float v)
+{
+    if constexpr ((FHIP_XFORM_NT & 2) != 0)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
 // Conv geometry as the kernels want it (decoded once on the host from fhip_conv_param).
 struct ConvGeom
 {

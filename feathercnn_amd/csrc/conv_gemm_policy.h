@@ -503,7 +503,7 @@ struct ConvGemmPolicy
                 }
                 // (selected element by element: a pointer to one of the two register arrays would send both to scratch memory)
                 if (wide)
-                    *reinterpret_cast<float4*>((second ? ptr2[0] : ptr[0]) + moff) = v;
+                    stg4_act<1>((second ? ptr2[0] : ptr[0]) + moff, v);
                 else
                 {
                     if (valid & 1u) (second ? ptr2[0] : ptr[0])[moff] = v.x;
@@ -539,7 +539,7 @@ struct ConvGemmPolicy
                 v.w = fmaxf(v.w, 0.f);
             }
             if (wide)
-                *reinterpret_cast<float4*>(ptr[0] + moff) = v;
+                stg4_act<1>(ptr[0] + moff, v);
             else
             {
                 if (valid & 1u) ptr[0][moff] = v.x;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams 
             }
         }
         if (vec)
-            *reinterpret_cast<float4*>(obase + o0) = make_float4(res[0], res[1], res[2], res[3]);
+            stg4_act<4>(obase + o0, make_float4(res[0], res[1], res[2], res[3]));
         else
         {
 #pragma unroll
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kern
                 }
             }
             if (o0 + 3 < nout)
-                *reinterpret_cast<float4*>(obase + o0) = make_float4(res[0], res[1], res[2], res[3]);
+                stg4_act<4>(obase + o0, make_float4(res[0], res[1], res[2], res[3]));
             else
             {
 #pragma unroll
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_band_kernel(const DwParams q
             }
             res[e] = apply_act(acc + bias, q.relu);
         }
-        *reinterpret_cast<float4*>(obase + (size_t)ly * WW + x0) = make_float4(res[0], res[1], res[2], res[3]);
+        stg4_act<4>(obase + (size_t)ly * WW + x0, make_float4(res[0], res[1], res[2], res[3]));
     }
 }
 

@@ -21,7 +21,8 @@
 //     accumulators hold four consecutive pixels: dwordx4 stores, no transpose, as in stream_gemm.h), the last 96 as three plain 32-column
 //     tiles -- with the A operand straight from the streamed kernel's packed image (CH / 2 coalesced dwords per lane and chunk, a chunk ahead);
 //   * a producer and a consumer share every SIMD, so the vector ALU work of chunk i + 1 issues under the MFMAs of chunk i; ONE barrier per chunk.
-// HBM sees the pair's input once (+ the two halo rows per band, from L2) and its output once; the depthwise output never exists.
+// HBM sees the pair's input once (+ the two halo rows per band, from L2 -- which takes the round-5 item order below: with round 4's order
+// the halo rows came over the fabric again, 1.35x the algorithmic bytes) and its output once; the depthwise output never exists.
 //
 // WHERE IT IS USED (round 4, measured): the kernel is memory-parallelism bound -- a persistent block keeps at most two chunks of requests in
 // flight -- so it pays where a pair is HBM-bound and the block is small enough for TWO blocks per CU: MobileNet-V1's first pair (32 -> 64
@@ -35,6 +36,9 @@
 
 #include "common.h"
 
+#ifndef FHIP_BAND_ORDER
+#define FHIP_BAND_ORDER 1 // 0: a contiguous share of the items per block (round 4), 1: rounds of XCD-contiguous items (round 5)
+#endif
 #ifndef FHIP_BAND_ABLATE
 #define FHIP_BAND_ABLATE 0 // measurement builds only (tools/dwpw_ab.sh): 1 no depthwise arithmetic, 2 no MFMAs, 4 no band fetch, 8 no stores
 #endif
@@ -113,9 +117,28 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
     // PERSISTENT blocks: a block takes a contiguous share of the work items (image, row group, block of output channels -- the channel blocks of
     // one band are neighbours: they read the same input band at the same time) and runs them as ONE chunk pipeline, so that the producers are
     // already two chunks into the next item while the consumers store the last one: no block start / end is ever exposed.
-    const int item0 = (int)((long long)q.bands * blockIdx.x / gridDim.x), item1 = (int)((long long)q.bands * (blockIdx.x + 1) / gridDim.x);
-    if (item0 >= item1) return;
-    const long long total_chunks = (long long)(item1 - item0) * NCH;
+    // ITEM ORDER (round 5).  Neighbouring bands share two of their four input rows.  With a contiguous share of the items per block (round 4)
+    // the blocks that run at the same time are half an image apart, a band's halo rows are long gone from the 4 MB L2 when its neighbour comes
+    // round, and every input row crosses the fabric twice (rocprofv3, MobileNet-V1 b256: 846 MB fetched for a 411 MB input).  Here the grid
+    // walks the items in rounds of gridDim.x, and inside a round the XCD blockIdx % 8 owns a contiguous eighth: at any moment an XCD's blocks
+    // work on consecutive bands, so a band's halo rows are its neighbour's rows, requested within microseconds of each other into the same L2.
+    // item(t) = item0 + t * step for t < n_items.
+    int item0, step, n_items;
+    if (FHIP_BAND_ORDER == 1 && (gridDim.x & 7) == 0)
+    {
+        item0 = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        step = gridDim.x;
+        n_items = item0 < q.bands ? (q.bands - item0 + step - 1) / step : 0;
+    }
+    else
+    {
+        item0 = (int)((long long)q.bands * blockIdx.x / gridDim.x);
+        step = 1;
+        n_items = (int)((long long)q.bands * (blockIdx.x + 1) / gridDim.x) - item0;
+    }
+    if (n_items <= 0) return;
+    const int item1 = item0 + n_items * step; // (exclusive bound of the block's walk)
+    const long long total_chunks = (long long)n_items * NCH;
     // ---- common prologue: pad columns of both bands (never written by the stager), taps + bias of all channels
     for (int i = tid; i < 2 * CH * RI; i += SH::THREADS)
     {
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
         if (++f_ch == NCH)
         {
             f_ch = 0;
-            ++f_item;
+            f_item += step;
         }
     };
     auto stash = [&](auto ch_c) { // chunk parity = band buffer = request set
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
         if (total_chunks > 3) fetch(I1{});
         __syncthreads(); // B tile 0, band 1
         long long j = 0;
-        for (int item = item0; item < item1; ++item)
+        for (int item = item0; item < item1; item += step)
         {
             static_for<NCH>([&](auto ch_c) {
                 constexpr int ch = decltype(ch_c)::value;
@@ -304,7 +327,7 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
         __syncthreads(); // band 0
         __syncthreads(); // B tile 0, band 1
         long long j = 0;
-        for (int item = item0; item < item1; ++item)
+        for (int item = item0; item < item1; item += step)
         {
             const int mt = item % q.m_tiles, band_id = item / q.m_tiles;
             const int n = band_id / q.groups, g = band_id - n * q.groups;
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(SH::THREADS, SH::BPC * SH::THREADS / 256) void dwpw
                                 v.z = fmaxf(v.z, 0.f);
                                 v.w = fmaxf(v.w, 0.f);
                             }
-                            *reinterpret_cast<float4*>(obase + (size_t)row * kstride + pix) = v;
+                            stg4_act<8>(obase + (size_t)row * kstride + pix, v);
                         }
                     }
                 }

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const SmallCParams q)
                     }
                     float* o = q.out + (((size_t)n * q.K + m) * q.OH + oy) * q.OW + ox;
                     if (ox + 3 < q.OW && (q.OW & 3) == 0)
-                        *reinterpret_cast<float4*>(o) = v;
+                        stg4_act<1>(o, v);
                     else
                     {
                         o[0] = v.x;
@@ -846,27 +846,23 @@ int igemm_twin_forward(const fhip_conv_param& a, const fhip_conv_param& b, int b
 // ---- the band-staged, wave-specialised form (dwpw_band.h) for MobileNet's first pair: a 3x3 / stride-1 depthwise layer with 32 channels on
 // 112-pixel rows + a 1x1 layer with a multiple of 64 output channels.  The row width, the stride and the channel count are template parameters
 // (constant divisions, fully unrolled chunk pipeline); the other pair geometries stay on ConvGemmPolicy<3|4>, which measured faster there.
+constexpr int kDwPwBandMaxK = 128; // measured at 64 (MobileNet-V1's first pair); beyond two channel blocks the redundant depthwise work outgrows the saving
 using Band112s1c32 = DwPwBandShape<112, 1, 2, 32, 8, 2, 4, 2>; // W, S, R, C, CH, consumer waves per pixel group, producer waves, blocks per CU
 static bool dwpw_band_applicable(const fhip_conv_param& dw, const fhip_conv_param& pw)
 {
     const int s = dw.stride_h > 0 ? dw.stride_h : 1;
     return dw.group == dw.input_channels && dw.kernel_h == 3 && dw.kernel_w == 3 && s == 1 && dw.stride_w == dw.stride_h && dw.pad_left == 1 &&
            dw.pad_top == 1 && dw.input_w == 112 && dw.output_w == 112 && dw.input_channels == 32 && pw.output_channels % 64 == 0 &&
+           pw.output_channels <= kDwPwBandMaxK && // a work item covers 64 output channels and redoes the band's depthwise pass per channel block
+
            (dw.activation == FHIP_ACT_NONE || dw.activation == FHIP_ACT_RELU) && (pw.activation == FHIP_ACT_NONE || pw.activation == FHIP_ACT_RELU);
 }
 
 template <class SH>
 static int dwpw_band_launch(const DwPwBandParams& q, int batch, hipStream_t s)
 {
-    static bool attr_set[64] = {false}; // dynamic LDS above 64 KB must be allowed once per kernel AND device
-    int dev = 0;
-    FHIP_CHECK_HIP(hipGetDevice(&dev));
     constexpr size_t lds = (size_t)SH::LDS_FLOATS * sizeof(float);
-    if (dev < 0 || dev >= 64 || !attr_set[dev])
-    {
-        FHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_band_kernel<SH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static_assert(lds <= 64 * 1024, "within the default dynamic-LDS limit: no hipFuncSetAttribute (no per-device state, nothing on the launch path a graph capture could trip over)");
     DwPwBandParams qq = q;
     qq.m_tiles = q.K / (32 * SH::CW);
     const long long items = (long long)batch * q.groups * qq.m_tiles;

@@ -993,7 +993,7 @@ int ConvLayer::Fuse(Layer* next, int level)
             return 0;
         // fhip_conv_can_fuse_dw_pw's profitable range -- or the band-staged kernel's pair (32 channels, stride 1, a multiple of 64 output channels:
         // MobileNet's first pair); the row width is only known at Reshape, where the pair falls back to its two kernels if it does not qualify
-        const bool band_pair = p.input_channels == 32 && p.stride_h == 1 && q.output_channels % 64 == 0;
+        const bool band_pair = p.input_channels == 32 && p.stride_h == 1 && q.output_channels % 64 == 0 && q.output_channels <= 128; // = dwpw_band_applicable's bound
         if (!band_pair && (q.output_channels <= 64 || q.output_channels >= (p.stride_h == 1 ? 160 : 400))) return 0;
         return 2; // the pass hands `next` over (fuse_layers)
     }

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const StreamGemmParams
         }
         float* o = op + (size_t)row * q.HW;
         if (!RAGGED || first_new == 0)
-            *reinterpret_cast<float4*>(o) = v;
+            stg4_act<1>(o, v);
         else
         {
             if (first_new <= 1) o[1] = v.y;

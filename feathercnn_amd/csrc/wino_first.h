@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 4) void wino_input_from_first_kernel(const Win
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
+        for (int j = 0; j < 8; ++j) st_scratch(vb + (size_t)(i * 8 + j) * xi_stride + lane_off, d[i][j]);
 }
 
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[i][j]), vrsrc, (int)voff, (int)(sbase + (unsigned)(i * 8 + j) * sstep), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[i][j]), vrsrc, (int)voff, (int)(sbase + (unsigned)(i * 8 + j) * sstep), (FHIP_XFORM_NT & 2) ? 2 : 0);
         }
         else
         {
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) (vb + (size_t)(i * 8 + j) * xi_stride)[lane_off] = d[i][j];
+                for (int j = 0; j < 8; ++j) st_scratch(vb + (size_t)(i * 8 + j) * xi_stride + lane_off, d[i][j]);
         }
     }
 }

@@ -18,7 +18,12 @@ namespace fhip
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int NBUF, int BK = 16, int OCC = 6>
+#ifndef FHIP_GLDS_NT
+#define FHIP_GLDS_NT 0 // default of the NT template parameters below (tools); the product's launches pass FHIP_M_NT_BIG / FHIP_M_NT_SMALL
+#endif
+// NT bit 0: the V pieces are requested with the non-temporal hint (aux = 2 of global_load_lds); bit 1: M leaves through `nt` stores
+// SPLIT: the launch carries row pieces behind its whole tiles (prm.tail_first / tail_parts); false = the plain kernel, untouched
+template <int NBUF, int BK = 16, int OCC = 6, int NT = FHIP_GLDS_NT, bool SPLIT = false>
 __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel(const WinoGemmPolicy::Params prm)
 {
     constexpr int BM = 128, BN = 64, EPI_LD = 36;
@@ -28,7 +33,22 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
     const int nwg = prm.batches * prm.m_tiles * prm.n_tiles;
-    int vid = xcd_remap(blockIdx.x, nwg);
+    // whole tiles first (XCD-aware order); behind them the row pieces of the last tiles, the pieces of one tile on one XCD (block b runs on
+    // XCD b % 8 and tail_first is a multiple of the CU count)
+    const int parts = SPLIT ? prm.tail_parts : 1;
+    const bool whole = !SPLIT || parts == 1 || (int)blockIdx.x < prm.tail_first;
+    int vid, part = 0;
+    if (!SPLIT || parts == 1)
+        vid = xcd_remap(blockIdx.x, nwg);
+    else if (whole)
+        vid = xcd_remap(blockIdx.x, prm.tail_first);
+    else
+    {
+        const int e = blockIdx.x - prm.tail_first, grp = e >> 3;
+        part = grp % parts;
+        vid = prm.tail_first + (grp / parts) * 8 + (e & 7);
+        if (vid >= nwg) return; // (tail tiles) not a multiple of 8: the surplus blocks of the last group
+    }
     const int mt = vid % prm.m_tiles;
     vid /= prm.m_tiles;
     const int nt = vid % prm.n_tiles;
@@ -57,7 +77,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
         for (int i = 0; i < RPW / 4; ++i)
         {
             const int r = min(kt * BK + brow + 4 * i, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp, (lds_void*)(base + BK * BM + (wave * RPW + 4 * i) * BN), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp, (lds_void*)(base + BK * BM + (wave * RPW + 4 * i) * BN), 16, 0, (NT & 1) ? 2 : 0);
         }
     };
 
@@ -77,7 +97,11 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int a_off = half * BM + wm * 64 + l31;
+    // rows of this wave inside the 128-row tile: a whole tile gives wave (wm, wn) rows 64 wm .. + 63 (two accumulators); a half piece
+    // (64 rows) gives it rows 64 part + 32 wm .. + 31, a quarter piece (32 rows) rows 32 part .. + 31 on the waves wm = 0 only (one accumulator)
+    const int row_off = whole ? wm * 64 : parts == 2 ? part * 64 + wm * 32 : part * 32;
+    const bool idle = SPLIT && !whole && parts == 4 && wm == 1; // still issues its share of the operand loads and meets every barrier
+    const int a_off = half * BM + row_off + l31;
     const int b_off = BK * BM + half * BN + wn * 32 + l31;
     int cur = 0;
     for (int kt = 0; kt < k_tiles; ++kt)
@@ -90,12 +114,24 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
 
         const float* as = lds + cur * BUF_FLOATS + a_off;
         const float* bs = lds + cur * BUF_FLOATS + b_off;
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp)
+        if (whole)
         {
-            const float fa0 = as[(2 * kp) * BM], fa1 = as[(2 * kp) * BM + 32], fb = bs[(2 * kp) * BN];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp)
+            {
+                const float fa0 = as[(2 * kp) * BM], fa1 = as[(2 * kp) * BM + 32], fb = bs[(2 * kp) * BN];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb, acc[1], 0, 0, 0);
+            }
+        }
+        else if (!idle)
+        {
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp)
+            {
+                const float fa0 = as[(2 * kp) * BM], fb = bs[(2 * kp) * BN];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb, acc[0], 0, 0, 0);
+            }
         }
         // my pieces of the NEXT tile have landed (the tile just issued may stay in flight), my LDS reads are done
         if (NBUF == 3 && more)
@@ -107,21 +143,31 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
     }
 
     // epilogue (gemm_core.h): per-wave LDS transpose, 16-byte row stores
+    if (idle) return;
     float* const scr = lds + wave * (32 * EPI_LD);
     const int e_row = lane >> 3, e_c4 = (lane & 7) * 4;
     float* mbase = prm.M + (size_t)xi * prm.Lm.xis + prm.Lm.col(n0) + wn * 32 + e_c4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
     {
+        if (i == 1 && !whole) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * half) * EPI_LD + l31] = acc[i][r];
-        const int mrow = m0 + wm * 64 + i * 32 + e_row;
+        const int mrow = m0 + row_off + i * 32 + e_row;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
         {
             const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * EPI_LD + e_c4]);
             const int m = mrow + q * 8;
-            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
+            if (m < prm.K)
+            {
+                if constexpr ((NT & ~3) != 0)
+                    stg4_asm<(NT & ~1)>(mbase + (size_t)m * prm.Lm.bp, v);
+                else if constexpr (NT & 2)
+                    stg4_nt(mbase + (size_t)m * prm.Lm.bp, v);
+                else
+                    *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
+            }
         }
     }
 }
@@ -131,6 +177,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
 // executed).  288 = 3 x 96 exactly, and 4 x 3 x 64 blocks are 3 per CU -- one round, everything resident.  Waves 4 x 1: a wave owns 32
 // rows x 96 columns = three 32x32 accumulators sharing one A fragment (1 A + 3 B LDS reads per 3 MFMAs).  B tile [16][96] is six 1-KB
 // LDS-DMA pieces (lane -> row e / 24, 16-byte column e % 24), A eight; two buffers (28 KB), 5 blocks per CU.
+template <int NT = FHIP_GLDS_NT>
 __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemmPolicy::Params prm)
 {
     constexpr int BM = 128, BN = 96, BK = 16, EPI_LD = 36, NBUF = 2;
@@ -168,12 +215,12 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
         float* bb = base + BK * BM;
         {
             const int r = min(kt * BK + b0_row, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b0_col, (lds_void*)(bb + wave * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b0_col, (lds_void*)(bb + wave * 256), 16, 0, (NT & 1) ? 2 : 0);
         }
         if (wave < 2)
         {
             const int r = min(kt * BK + b1_row, prm.C - 1);
-            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b1_col, (lds_void*)(bb + (wave + 4) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcB + (size_t)r * prm.Lv.bp + b1_col, (lds_void*)(bb + (wave + 4) * 256), 16, 0, (NT & 1) ? 2 : 0);
         }
     };
 
@@ -222,9 +269,41 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
         {
             const float4 v = *reinterpret_cast<const float4*>(&scr[(q * 8 + e_row) * EPI_LD + e_c4]);
             const int m = mrow + q * 8;
-            if (m < prm.K) *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
+            if (m < prm.K)
+            {
+                if constexpr ((NT & ~3) != 0)
+                    stg4_asm<(NT & ~1)>(mbase + (size_t)m * prm.Lm.bp, v);
+                else if constexpr ((NT & 2) != 0)
+                    stg4_nt(mbase + (size_t)m * prm.Lm.bp, v);
+                else
+                    *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
+            }
         }
     }
+}
+
+// Row split of the last tiles (round 5).  A launch of `tiles` whole 128 x 64 tiles on `cus` CUs leaves tiles % cus CUs with one tile more
+// than the others; when that remainder is at most a quarter (half) of the CUs, its tiles are cut into 4 (2) row pieces of 32 (64) rows --
+// one block each, so every CU gets at most one PIECE more.  ResNet-50 b64's res5 layers (F(4x4,3x3): 36 x 4 x 4 = 576 tiles = 2.25 per
+// CU) run 2 tiles + 1 quarter per CU instead of 3 tiles on a quarter of the CUs.  Only where a tile is a large share of a CU's work
+// (<= max_rounds tiles per CU): measured with tools/gemm_bench.hip GEMM_SPLIT=1.  -> tail_first (== tiles: no split), tail_parts
+inline void wino_gemm_row_split(int tiles, int cus, int max_rounds, int& tail_first, int& tail_parts)
+{
+    tail_first = tiles;
+    tail_parts = 1;
+    const int r = tiles % cus;
+    if (r == 0 || tiles < cus || tiles > max_rounds * cus || (cus & 7)) return;
+    if (r * 4 <= cus)
+        tail_parts = 4;
+    else if (r * 2 <= cus)
+        tail_parts = 2;
+    else
+        return;
+    tail_first = tiles - r;
+}
+inline int wino_gemm_row_split_grid(int tiles, int tail_first, int tail_parts)
+{
+    return tail_parts == 1 ? tiles : tail_first + round_up(tiles - tail_first, 8) * tail_parts;
 }
 
 // does the 96-column tile pad fewer columns than the 64-column one?  (pure function of the column count)

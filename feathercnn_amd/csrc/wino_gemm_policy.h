@@ -9,17 +9,26 @@
 namespace fhip
 {
 
-struct WinoGemmPolicy
+struct WinoGemmParams
 {
-    struct Params
-    {
-        int batches, m_tiles, n_tiles, k_tiles;
-        const float* U;
-        const float* V;
-        float* M;
-        int C, K, Cp, Kp, Pp;
-        WinoLayout Lv, Lm; // where V (rows = C) and M (rows = K) live; the column tile divides their column block (wino_layout.h)
-    };
+    int batches, m_tiles, n_tiles, k_tiles;
+    const float* U;
+    const float* V;
+    float* M;
+    int C, K, Cp, Kp, Pp;
+    WinoLayout Lv, Lm; // where V (rows = C) and M (rows = K) live; the column tile divides their column block (wino_layout.h)
+    // wino_gemm_glds_kernel only (round 5): tiles [tail_first, batches * m_tiles * n_tiles) are cut into tail_parts (2 / 4) ROW pieces of 64 / 32
+    // rows, one block each -- the remainder of the tile count over the CU count spread over all CUs instead of a whole tile more on some
+    // (wino_gemm_row_split).  tail_parts = 1: every block is a whole tile.
+    int tail_first = 0, tail_parts = 1;
+};
+
+// NT bit 0: V loads carry `nt` (every V element is read by exactly one block when the row tile covers all of K: m_tiles = 1);
+//    bit 1: M stores carry `nt` (M is written once and read once, by the next launch)
+template <int NT>
+struct WinoGemmPolicyT
+{
+    typedef WinoGemmParams Params;
     static constexpr int EXTRA_LDS_FLOATS = 0;
     static __device__ void stage_extra(const Params&, float*, int, int) {}
     static __device__ int k_count(const Params& p, int) { return p.k_tiles; }
@@ -43,7 +52,9 @@ struct WinoGemmPolicy
         {
             // unconditional: rows past C re-read row C-1 and are zeroed at LDS-write time
             ok = krow < p.C ? 0xfu : 0u;
-            return *reinterpret_cast<const float4*>(base + (size_t)min(krow, p.C - 1) * p.Lv.bp);
+            const float* q = base + (size_t)min(krow, p.C - 1) * p.Lv.bp;
+            if constexpr (NT & 1) return ldg4_nt(q);
+            return *reinterpret_cast<const float4*>(q);
         }
     };
     struct Store
@@ -52,12 +63,34 @@ struct WinoGemmPolicy
         __device__ Store(const Params& p, int xi, int n4) : base(p.M + (size_t)xi * p.Lm.xis + p.Lm.col(n4)) {}
         __device__ void put4(const Params& p, int m, float4 v) const
         {
-            if (m < p.K) *reinterpret_cast<float4*>(base + (size_t)m * p.Lm.bp) = v; // Pp is a multiple of the column tile
+            if (m >= p.K) return; // Pp is a multiple of the column tile
+            if constexpr ((NT & ~3) != 0)
+                stg4_asm<(NT & ~1)>(base + (size_t)m * p.Lm.bp, v);
+            else if constexpr (NT & 2)
+                stg4_nt(base + (size_t)m * p.Lm.bp, v);
+            else
+                *reinterpret_cast<float4*>(base + (size_t)m * p.Lm.bp) = v;
         }
         __device__ float4 residual4(const Params&, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
         __device__ void put4b(const Params& p, int m, float4 v, float, float4) const { put4(p, m, v); }
     };
 };
 
+// Cache policy of the M stores, by the size of M (winograd_tile_gemm): FHIP_M_NT_BIG for an M of at least FHIP_M_NT_BYTES, else FHIP_M_NT_SMALL
+// (0 plain, 2 `nt`, 4 `sc1` write-through, 6 `sc1 nt`).  Round 5, tools/variant_ab.sh: see DESIGN.md 3.10.
+#ifndef FHIP_M_NT_BIG
+#define FHIP_M_NT_BIG 2
+#endif
+#ifndef FHIP_M_NT_SMALL
+#define FHIP_M_NT_SMALL 4
+#endif
+// V loads of the register-staged kernel (K <= 64, or C < 128: one row tile covers all of K, so every V element is read by exactly one block)
+#ifndef FHIP_V_NT_ONCE
+#define FHIP_V_NT_ONCE 1
+#endif
+#ifndef FHIP_M_NT_BYTES
+#define FHIP_M_NT_BYTES (150u << 20)
+#endif
+typedef WinoGemmPolicyT<0> WinoGemmPolicy; // parameter block + plain accesses; the launches pick WinoGemmPolicyT<FHIP_M_NT_*>
 
 } // namespace fhip

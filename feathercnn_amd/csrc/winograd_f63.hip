@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(float* __rest
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * xi_stride] = d[i][j];
+        for (int j = 0; j < 8; ++j) st_scratch(vp + (size_t)(i * 8 + j) * xi_stride, d[i][j]);
 }
 
 } // namespace fhip
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(float* __res
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[i][j] = mp[(size_t)(i * 8 + j) * xi_stride];
+        for (int j = 0; j < 8; ++j) m[i][j] = ld_scratch(mp + (size_t)(i * 8 + j) * xi_stride);
 
     float tmp[6][8];
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[i][j] = mp[(size_t)(i * 8 + j) * xi_stride];
+            for (int j = 0; j < 8; ++j) m[i][j] = ld_scratch(mp + (size_t)(i * 8 + j) * xi_stride);
         float tmp[6][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
             if (a < urows[ul])
             {
                 const float4 v = *reinterpret_cast<const float4*>(tile + ((size_t)ul * R + a) * g.LDW + 4 * x4);
-                *reinterpret_cast<float4*>(out + ubase[ul] + (long long)a * OWo + 4 * x4) = v;
+                stg4_act<2>(out + ubase[ul] + (long long)a * OWo + 4 * x4, v);
             }
         }
     }
@@ -356,6 +356,145 @@ __global__ __launch_bounds__(256) void wino_output_transform_staged_kernel(float
             const int ul = row / R, a = row - ul * R;
             if (a < urows[ul]) out[ubase[ul] + (long long)a * OWo + x] = tile[((size_t)ul * R + a) * g.LDW + x];
         }
+    }
+}
+
+// K4, LDS-staged and PERSISTENT (round 5): the staged kernel above as a block that walks work items -- item = (output channel k, group of
+// UB tile rows), k-major so that a block's consecutive items are consecutive column runs of M -- with the NEXT item's 64 M values per lane
+// requested right after the barrier, before this item's rows leave the LDS: loads and stores of one block overlap, the form that took the
+// chained transform from 0.49 to 0.55 of the HBM rate (wino_chain_kernel).  Same butterflies on the same values in the same order: the output
+// is bit-identical to the one-shot kernel's.  Used where the one-shot grid is more than one round of resident blocks (ResNet-50 b64's 56-
+// and 28-pixel 3x3 layers); a grid that is resident at once keeps the one-shot kernel.
+template <bool HAS_BIAS, bool RELU, bool POOL>
+__global__ __launch_bounds__(256, 3) void wino_output_transform_persist_kernel(float* __restrict__ out, const float* __restrict__ M,
+                                                                              const float* __restrict__ bias, const WinoXformParams q,
+                                                                              const WinoStaged g, const int xblocks, const int items)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const tile = smem;
+    long long* const ubase = reinterpret_cast<long long*>(smem + (size_t)g.UB * g.R * g.LDW);
+    int* const urows = reinterpret_cast<int*>(ubase + g.UB);
+
+    const int tid = threadIdx.x;
+    const int unit_l = tid / q.TX, tx = tid - unit_l * q.TX;
+    const bool lane_in = unit_l < g.UB;
+    // the XCD blockIdx % 8 owns a contiguous eighth of the items, its blocks take neighbouring items at the same time
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, xcd_blocks = (gridDim.x + 7 - xcd) >> 3;
+    const int i_lo = (int)((long long)items * xcd / 8), i_hi = (int)((long long)items * (xcd + 1) / 8);
+    const size_t xi_stride = q.Lm.xis;
+
+    float m[8][8];
+    auto fetch = [&](int item) {
+        // clamped and unconditional (a load under a branch is waited for on the spot)
+        const int k = item / xblocks, bx = item - k * xblocks;
+        const int u = min(bx * g.UB + (lane_in ? unit_l : 0), g.units - 1);
+        const float* mp = M + (size_t)k * q.Lm.bp + q.Lm.col(u * q.TX + tx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) m[i][jj] = ld_scratch(mp + (size_t)(i * 8 + jj) * xi_stride);
+    };
+    int item = i_lo + j;
+    if (item < i_hi) fetch(item);
+    for (; item < i_hi; item += xcd_blocks)
+    {
+        const int k = item / xblocks, u0 = (item - k * xblocks) * g.UB;
+        if (tid < g.UB)
+        {
+            const int u = u0 + tid;
+            int rows = 0;
+            long long base = 0;
+            if (u < g.units)
+            {
+                const int n = u / g.TY, ty = u - n * g.TY;
+                rows = min(6, q.OH - 6 * ty);
+                base = (((long long)n * q.K + k) * q.OH + 6 * ty) * q.OW;
+                if (POOL)
+                {
+                    rows >>= 1;
+                    base = (((long long)n * q.K + k) * (q.OH >> 1) + 3 * ty) * (q.OW >> 1);
+                }
+            }
+            ubase[tid] = base;
+            urows[tid] = rows;
+        }
+        if (lane_in && (u0 + unit_l) < g.units)
+        {
+            float tmp[6][8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                at6(m[0][jj], m[1][jj], m[2][jj], m[3][jj], m[4][jj], m[5][jj], m[6][jj], m[7][jj], tmp[0][jj], tmp[1][jj], tmp[2][jj], tmp[3][jj],
+                    tmp[4][jj], tmp[5][jj]);
+            const float b = HAS_BIAS ? bias[k] : 0.f;
+            float* tp = tile + ((size_t)unit_l * g.R) * g.LDW + (POOL ? 3 : 6) * tx;
+            float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+            {
+                float y[6];
+                at6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], tmp[a][6], tmp[a][7], y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb)
+                {
+                    float v = y[bb] + b;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    y[bb] = v;
+                }
+                if (POOL)
+                {
+                    const float h0 = fmaxf(y[0], y[1]), h1 = fmaxf(y[2], y[3]), h2 = fmaxf(y[4], y[5]);
+                    if ((a & 1) == 0)
+                    {
+                        prev0 = h0;
+                        prev1 = h1;
+                        prev2 = h2;
+                    }
+                    else
+                    {
+                        float* t = tp + (size_t)(a >> 1) * g.LDW;
+                        t[0] = fmaxf(prev0, h0);
+                        t[1] = fmaxf(prev1, h1);
+                        t[2] = fmaxf(prev2, h2);
+                    }
+                    continue;
+                }
+                float2* t2 = reinterpret_cast<float2*>(tp + (size_t)a * g.LDW);
+                t2[0] = make_float2(y[0], y[1]);
+                t2[1] = make_float2(y[2], y[3]);
+                t2[2] = make_float2(y[4], y[5]);
+            }
+        }
+        __syncthreads();
+        // ---- the next item's tiles: in flight while this item's rows are copied out
+        if (item + xcd_blocks < i_hi) fetch(item + xcd_blocks);
+        __builtin_amdgcn_sched_barrier(0); // hipcc would sink the loads to their uses
+        const int R = POOL ? 3 : 6, OWo = POOL ? q.OW >> 1 : q.OW;
+        if ((OWo & 3) == 0)
+        {
+            const int w4 = OWo >> 2;
+            const int total = g.UB * R * w4;
+            for (int idx = tid; idx < total; idx += 256)
+            {
+                const int row = idx / w4, x4 = idx - row * w4;
+                const int ul = row / R, a = row - ul * R;
+                if (a < urows[ul])
+                {
+                    const float4 v = *reinterpret_cast<const float4*>(tile + ((size_t)ul * R + a) * g.LDW + 4 * x4);
+                    stg4_act<2>(out + ubase[ul] + (long long)a * OWo + 4 * x4, v);
+                }
+            }
+        }
+        else
+        {
+            const int total = g.UB * R * OWo;
+            for (int idx = tid; idx < total; idx += 256)
+            {
+                const int row = idx / OWo, x = idx - row * OWo;
+                const int ul = row / R, a = row - ul * R;
+                if (a < urows[ul]) out[ubase[ul] + (long long)a * OWo + x] = tile[((size_t)ul * R + a) * g.LDW + x];
+            }
+        }
+        __syncthreads(); // the rows are out (and ubase / urows read): the next item may overwrite the LDS
     }
 }
 
@@ -424,7 +563,7 @@ __global__ __launch_bounds__(512, 3) void wino_chain_kernel(float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) m[i][jj] = mp[(size_t)(i * 8 + jj) * xi_stride];
+            for (int jj = 0; jj < 8; ++jj) m[i][jj] = ld_scratch(mp + (size_t)(i * 8 + jj) * xi_stride);
     };
     int unit = u_lo + j;
     if (unit < u_hi) fetch(unit, t);
@@ -526,7 +665,7 @@ __global__ __launch_bounds__(512, 3) void wino_chain_kernel(float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) vp[(size_t)(i * 8 + jj) * xi_stride2] = d[i][jj];
+                for (int jj = 0; jj < 8; ++jj) st_scratch(vp + (size_t)(i * 8 + jj) * xi_stride2, d[i][jj]);
         }
         __syncthreads(); // the windows are read: the next phase 1 may overwrite the planes
     }
@@ -621,7 +760,7 @@ __global__ __launch_bounds__(512, 3) void wino_input_staged_kernel(float* __rest
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) vp[(size_t)(i * 8 + jj) * xi_stride2] = d[i][jj];
+                for (int jj = 0; jj < 8; ++jj) st_scratch(vp + (size_t)(i * 8 + jj) * xi_stride2, d[i][jj]);
         }
         __syncthreads(); // the windows are read: the next copies may overwrite the planes
     }
@@ -720,7 +859,7 @@ __global__ __launch_bounds__(256) void wino43_input_transform_kernel(float* __re
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) vp[(size_t)(i * 6 + j) * xi_stride] = d[i][j];
+        for (int j = 0; j < 6; ++j) st_scratch(vp + (size_t)(i * 6 + j) * xi_stride, d[i][j]);
 }
 
 // Y = A^T m A, + bias, ReLU, clipped 4x4 store.  Planes of at most 8 x 8: a (image, channel) plane is the 2 x 2 tiles of four consecutive lanes.
@@ -739,7 +878,7 @@ __global__ __launch_bounds__(256) void wino43_output_transform_kernel(float* __r
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = mp[(size_t)(i * 6 + j) * xi_stride];
+        for (int j = 0; j < 6; ++j) m[i][j] = ld_scratch(mp + (size_t)(i * 6 + j) * xi_stride);
     float tmp[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) at4(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j]);
@@ -772,6 +911,14 @@ constexpr int kWinoColTile = 128; // column padding of V / M
 constexpr int kWinoKTile = 16;    // reduction padding of U
 
 static bool wino_small_m(int K) { return K <= 64; }
+#ifndef FHIP_ROW_SPLIT_ROUNDS
+#define FHIP_ROW_SPLIT_ROUNDS 8
+#endif
+#ifndef FHIP_K4_PERSIST
+#define FHIP_K4_PERSIST 3
+#endif
+constexpr size_t kK4PersistBlocksPerCu = FHIP_K4_PERSIST; // persistent staged output transform: resident blocks per CU (0: always the one-shot kernel)
+constexpr int kWinoRowSplitMaxRounds = FHIP_ROW_SPLIT_ROUNDS; // wino_gemm_row_split: launches of at most this many tiles per CU (0: never)
 
 // F(4x4,3x3) instead of F(6x6,3x3): planes of at most 8 output pixels per side on which 4 x 4 output tiles need fewer (tile, frequency point)
 // pairs than 6 x 6 ones -- 7 and 8 pixels per side (2 x 2 x 36 = 144 against 2 x 2 x 64 = 256); 5- and 6-pixel planes are ONE F(6,3) tile.
@@ -885,6 +1032,7 @@ static bool winograd_input_staged(const fhip_conv_param& p, int batch, const fhi
     if (p.pad_left != 1 || p.pad_top != 1 || p.pad_right != 1 || p.pad_bottom != 1) return false;
     const int hw = p.input_h * p.input_w;
     if (hw & 3) return false;
+    if (reinterpret_cast<uintptr_t>(input) & 15) return false; // whole planes as aligned 16-byte vectors: a 4-byte-aligned tensor takes the direct kernel
     WinoChain g;
     g.K = p.input_channels;
     g.N = batch;
@@ -1036,6 +1184,39 @@ int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_para
     return FHIP_OK;
 }
 
+template <int NT>
+static void wino_tile_gemm_launch(WinoGemmPolicy::Params& g, int columns, hipStream_t s)
+{
+    if (wino_small_m(g.K))
+    {
+        g.m_tiles = g.Kp / WinoShapeSmallM::BM;
+        g.n_tiles = ceil_div(columns, WinoShapeSmallM::BN); // Pp is a multiple of every BN: no pure-padding tiles
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicyT<NT | FHIP_V_NT_ONCE>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                           dim3(WinoShapeSmallM::THREADS), 0, s, g);
+        return;
+    }
+    g.m_tiles = g.Kp / WinoShapeBig::BM;
+    g.n_tiles = ceil_div(columns, WinoShapeBig::BN);
+    if (g.k_tiles >= 8 && wino_gemm_prefers_96(columns))
+    {
+        // column counts that 64-column tiles pad by a third of a tile or more (VGG-16 conv5 b32: 288 = 3 x 96)
+        g.n_tiles = ceil_div(columns, 96);
+        hipLaunchKernelGGL(wino_gemm_glds96_kernel<NT>, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
+    }
+    else if (g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
+    {
+        const int tiles = g.batches * g.m_tiles * g.n_tiles;
+        wino_gemm_row_split(tiles, device_compute_units(), kWinoRowSplitMaxRounds, g.tail_first, g.tail_parts);
+        if (g.tail_parts > 1)
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT, true>), dim3(wino_gemm_row_split_grid(tiles, g.tail_first, g.tail_parts)), dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT>), dim3(tiles), dim3(256), 0, s, g);
+    }
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicyT<NT | FHIP_V_NT_ONCE>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                           dim3(WinoShapeBig::THREADS), 0, s, g);
+}
+
 int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const float* u, const float* v, hipStream_t s)
 {
     fhip_winograd_plan pl;
@@ -1055,31 +1236,29 @@ int winograd_tile_gemm(const fhip_conv_param& p, int batch, float* m, const floa
     g.Lm = wino_layout(g.K, g.Pp, pl.column_block, pl.frequency_points);
     g.k_tiles = g.Cp / kWinoKTile;
     StageTimer tm(FHIP_STAGE_WINO_GEMM, s);
-    if (wino_small_m(g.K))
-    {
-        g.m_tiles = g.Kp / WinoShapeSmallM::BM;
-        g.n_tiles = ceil_div(pl.columns, WinoShapeSmallM::BN); // Pp is a multiple of every BN: no pure-padding tiles
-        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
-                           dim3(WinoShapeSmallM::THREADS), 0, s, g);
-    }
+    // M is written once here and read once by the next launch.  A large M cannot stay in any cache until then: its stores take the
+    // streaming policy FHIP_M_NT_BIG; a small one keeps FHIP_M_NT_SMALL (wino_gemm_policy.h)
+    const bool big_m = (size_t)pl.frequency_points * g.K * g.Pp * sizeof(float) >= (size_t)FHIP_M_NT_BYTES;
+    if (big_m)
+        wino_tile_gemm_launch<FHIP_M_NT_BIG>(g, pl.columns, s);
     else
-    {
-        g.m_tiles = g.Kp / WinoShapeBig::BM;
-        g.n_tiles = ceil_div(pl.columns, WinoShapeBig::BN);
-        if (g.k_tiles >= 8 && wino_gemm_prefers_96(pl.columns))
-        {
-            // column counts that 64-column tiles pad by a third of a tile or more (VGG-16 conv5 b32: 288 = 3 x 96)
-            g.n_tiles = ceil_div(pl.columns, 96);
-            hipLaunchKernelGGL(wino_gemm_glds96_kernel, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
-        }
-        else if (g.k_tiles >= 8) // C = 64 (4 k-tiles, HBM bound): the register-staged loop is 6 % faster (83.9 vs 78.7 TF)
-            hipLaunchKernelGGL(wino_gemm_glds_kernel<2>, dim3(g.batches * g.m_tiles * g.n_tiles), dim3(256), 0, s, g);
-        else
-            hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicy>), dim3(g.batches * g.m_tiles * g.n_tiles),
-                               dim3(WinoShapeBig::THREADS), 0, s, g);
-    }
+        wino_tile_gemm_launch<FHIP_M_NT_SMALL>(g, pl.columns, s);
     FHIP_CHECK_HIP(hipGetLastError());
     return FHIP_OK;
+}
+
+template <bool POOL>
+static void launch_staged_persist(dim3 grid, size_t lds, hipStream_t s, bool has_bias, bool relu, float* output, const float* m, const float* bias,
+                                  const WinoXformParams& q, const WinoStaged& g, int xblocks, int items)
+{
+    if (has_bias && relu)
+        hipLaunchKernelGGL((wino_output_transform_persist_kernel<true, true, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g, xblocks, items);
+    else if (has_bias)
+        hipLaunchKernelGGL((wino_output_transform_persist_kernel<true, false, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g, xblocks, items);
+    else if (relu)
+        hipLaunchKernelGGL((wino_output_transform_persist_kernel<false, true, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g, xblocks, items);
+    else
+        hipLaunchKernelGGL((wino_output_transform_persist_kernel<false, false, POOL>), grid, dim3(256), lds, s, output, m, bias, q, g, xblocks, items);
 }
 
 template <bool POOL>
@@ -1139,7 +1318,18 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
         g.LDW = round_up(g.R * q.TX, 4);
         const size_t lds = (size_t)g.UB * g.R * g.LDW * sizeof(float) + (size_t)g.UB * (sizeof(long long) + sizeof(int));
         dim3 sgrid(ceil_div(g.units, g.UB), q.K);
-        if (pool)
+        // more work items than blocks that are resident at once: persistent blocks with the next item's loads under this item's stores
+        const long long items = (long long)sgrid.x * sgrid.y;
+        const int resident = device_compute_units() * (int)std::min<size_t>(kK4PersistBlocksPerCu, (160 * 1024) / lds);
+        if (kK4PersistBlocksPerCu > 0 && items > resident && items <= 0x7fffffffLL && lds <= 64 * 1024)
+        {
+            const dim3 pgrid((unsigned)(resident + 7) & ~7u);
+            if (pool)
+                launch_staged_persist<true>(pgrid, lds, s, has_bias, relu, output, m, bias, q, g, (int)sgrid.x, (int)items);
+            else
+                launch_staged_persist<false>(pgrid, lds, s, has_bias, relu, output, m, bias, q, g, (int)sgrid.x, (int)items);
+        }
+        else if (pool)
             launch_staged<true>(sgrid, lds, s, has_bias, relu, output, m, bias, q, g);
         else
             launch_staged<false>(sgrid, lds, s, has_bias, relu, output, m, bias, q, g);

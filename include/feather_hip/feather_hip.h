@@ -12,6 +12,12 @@
  *   - an explicit `batch` (the reference is N=1: src/layers/conv_layer.h:107);
  *   - sizes are BYTES in size_t (the reference reports float counts in int, booster.h:151);
  *   - `num_threads` is gone; a stream takes its place.
+ *
+ * Alignment.  Tensor pointers need 4-byte alignment, nothing more: the kernels that move whole planes as aligned 16-byte vectors check the
+ * pointer and fall back to their dword forms (pooling fast paths, the LDS-staged Winograd input transform), and the ones that issue 16-byte
+ * accesses at 4-byte-aligned addresses BY DESIGN (1x1 convolutions on planes that are not a multiple of 4 pixels, the staged Winograd output
+ * stores) rely on the unaligned-access mode gfx9 devices run in under ROCm (SH_MEM_CONFIG.ALIGNMENT_MODE = unaligned, the driver default).
+ * 16-byte-aligned tensors -- what hipMalloc, torch and the Net runtime's blobs give (256 bytes) -- are what every fast path is tuned for.
  */
 #ifndef FEATHER_HIP_H_
 #define FEATHER_HIP_H_

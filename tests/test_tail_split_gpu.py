@@ -34,10 +34,22 @@ def _cus():
     return torch.cuda.get_device_properties(0).multi_processor_count
 
 
+def _for_this_device(c, k, h, w, s, batch):
+    """The listed geometries are cut for the MI355X's 256 CUs.  On another CU count the same situation -- one full round of 128 x 64 tiles
+    plus two whole column tiles -- is rebuilt from the count (K = 256: two row tiles, cus / 2 + 2 column tiles of 64 pixels) for the 16-byte
+    column mode and the strided mode; the pixel-slot mode (7 x 7 planes) has no such closed form and is skipped there, loudly."""
+    cus = _cus()
+    if cus == 256:
+        return c, k, h, w, s, batch
+    if h == 7 or cus % 2:
+        pytest.skip(f"no derived tail geometry for {cus} CUs in this mode (listed ones assume 256)")
+    n_tiles = cus // 2 + 2
+    return (128, 256, 16, 4 * n_tiles, 1, 1) if s == 1 else (128, 256, 32, 8 * n_tiles, 2, 1)
+
+
 @pytest.mark.parametrize("c,k,h,w,s,batch", TAIL)
 def test_tail_columns_in_pieces_match_the_oracle(cuda, c, k, h, w, s, batch):
-    if _cus() != 256:
-        pytest.skip("geometries chosen for 256 CUs")
+    c, k, h, w, s, batch = _for_this_device(c, k, h, w, s, batch)
     g, x, wt, b, p, layer = _layer(cuda, c, k, h, w, s, batch)
     assert layer.buffer_bytes > 0, "the tail split needs scratch for its partial sums: this geometry should take it"
     want = oracle.best().forward(g, x, wt, b)
@@ -64,8 +76,7 @@ def test_neighbouring_geometries_keep_the_plain_launch(cuda, c, k, h, w, s, batc
 def test_tail_split_with_fused_residual(cuda, c, k, h, w, s, batch):
     from feathercnn_amd import _lib
     from feathercnn_amd.booster import IM2COL
-    if _cus() != 256:
-        pytest.skip("geometries chosen for 256 CUs")
+    c, k, h, w, s, batch = _for_this_device(c, k, h, w, s, batch)
     lib = _lib.load_library()
     g, x, wt, b, p0, plain = _layer(cuda, c, k, h, w, s, batch, act=0)
     xt = torch.from_numpy(x).to(cuda)

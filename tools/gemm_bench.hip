@@ -43,10 +43,11 @@ static int g_cus = 256;
 static int g_batches = 64;
 static int g_ref_pp = 0;
 static int g_bp = 0; // column block of V / M (GEMM_BP)
+static int g_split_rounds = 0; // GEMM_SPLIT: wino_gemm_row_split's max_rounds for V0 == 3 (0 = whole tiles only)
 static int g_c64_blocks = 2; // persistent blocks per CU of wino_gemm_c64_kernel
 static long long* g_prof = nullptr;
 
-template <class Shape, int ABLATE, int V0 = 0>
+template <class Shape, int ABLATE, int V0 = 0, int NT = 0>
 double run(const char* name, const Case& cs, float* U, float* V, float* M, int reps)
 {
     WinoGemmPolicy::Params g;
@@ -74,9 +75,21 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
     g.Lm = wino_layout(g.K, g.Pp, bp);
     const int tiles = g.batches * g.m_tiles * g.n_tiles;
     dim3 grid(tiles);
+    if (V0 == 3 && g_split_rounds)
+    {
+        wino_gemm_row_split(tiles, g_cus, g_split_rounds, g.tail_first, g.tail_parts);
+        grid = dim3(wino_gemm_row_split_grid(tiles, g.tail_first, g.tail_parts));
+    }
     auto launch = [&]() {
         if constexpr (V0 == 3)
-            hipLaunchKernelGGL((wino_gemm_glds_kernel<2>), grid, dim3(256), 0, 0, g);
+        {
+            if (g.tail_parts > 1)
+                hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT, true>), grid, dim3(256), 0, 0, g);
+            else
+                hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT>), grid, dim3(256), 0, 0, g);
+        }
+        else if constexpr (V0 == 9) // the product's main loop itself (not the probe copy), with the NT hints of WinoGemmPolicyT
+            hipLaunchKernelGGL((gemm_mfma_kernel<Shape, WinoGemmPolicyT<NT>>), grid, dim3(Shape::THREADS), 0, 0, g);
         else if constexpr (V0 == 4)
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 5>), grid, dim3(256), 0, 0, g);
         else if constexpr (V0 == 5)
@@ -115,7 +128,7 @@ double run(const char* name, const Case& cs, float* U, float* V, float* M, int r
             got[w].resize(plane);
             CK(hipMemcpy(got[w].data(), M + (size_t)(w ? g_batches - 1 : 0) * plane, plane * 4, hipMemcpyDeviceToHost));
         }
-        if (fresh && ABLATE == 0 && V0 == 0 && !bp)
+        if (fresh && ABLATE == 0 && (V0 == 0 || (V0 == 3 && !g_split_rounds && getenv("GEMM_SPLIT"))) && !bp)
         {
             ref[0] = got[0];
             ref[1] = got[1];
@@ -147,7 +160,12 @@ int main(int argc, char** argv)
     // (GEMM_RESNET: ResNet-50's 3x3 layers at batch 64 instead)
     const Case vgg[] = {{64, 64, 46208}, {64, 128, 11552}, {128, 128, 11552}, {128, 256, 3200}, {256, 256, 3200}, {256, 512, 800}, {512, 512, 800}, {512, 512, 288}};
     const Case resnet[] = {{64, 64, 6400}, {256, 256, 576}, {512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {512, 512, 256}, {256, 256, 576}, {512, 512, 256}};
-    const Case* cases_p = getenv("GEMM_RESNET") ? resnet : vgg;
+    // GEMM_TAIL: what a partial last round costs -- the LDS-DMA kernel on column counts that make whole rounds of 6 blocks per CU next to VGG-16's
+    const Case tail[] = {{512, 512, 768}, {512, 512, 800}, {512, 512, 1152}, {256, 256, 3072}, {256, 256, 3200}, {256, 256, 4608}, {128, 128, 12288}, {128, 128, 11552}};
+    // GEMM_SPLIT: the row split of the last tiles -- ResNet-50 b64's res5 (36 frequency points, set GEMM_BATCHES=36), res3, res4 on 64-column tiles, VGG-16's conv2_2
+    const Case split[] = {{512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {128, 128, 11552}, {512, 512, 256}, {128, 128, 1600}, {256, 256, 576}, {128, 128, 11552}};
+    if (getenv("GEMM_BATCHES")) g_batches = atoi(getenv("GEMM_BATCHES"));
+    const Case* cases_p = getenv("GEMM_SPLIT") ? split : getenv("GEMM_TAIL") ? tail : getenv("GEMM_RESNET") ? resnet : vgg;
     Case cases[8];
     for (int i = 0; i < 8; ++i) cases[i] = cases_p[i];
     size_t maxU = 0, maxV = 0, maxM = 0;
@@ -188,6 +206,69 @@ int main(int argc, char** argv)
     {
         if (getenv("GEMM_ONE") && !(c.C == 512 && c.K == 512 && c.P == 800)) continue;
         printf("case C=%d K=%d P=%d\n", c.C, c.K, c.P);
+        if (getenv("GEMM_SPLIT"))
+        {
+            if (&c - cases >= 4) continue;
+            for (int round = 0; round < 4; ++round)
+            {
+                g_split_rounds = 0;
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds whole tiles", c, U, V, M, reps);
+                g_split_rounds = 64;
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds row split", c, U, V, M, reps);
+                g_split_rounds = 0;
+                if (c.P <= 576) run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 7>("128x96 glds", c, U, V, M, reps);
+            }
+            continue;
+        }
+        if (getenv("GEMM_TAIL"))
+        {
+            for (int round = 0; round < 3; ++round) run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds (product)", c, U, V, M, reps);
+            continue;
+        }
+        if (getenv("GEMM_R5"))
+        {
+            // round 5: non-temporal hints on the read-once / write-once streams, wider tiles for conv2_1, and what a partial last round costs
+            for (int round = 0; round < 3; ++round)
+            {
+                if (c.K <= 64)
+                {
+                    for (int bp : {1024})
+                    {
+                        g_bp = bp;
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 9, 0>("64x128 reg plain BP1024", c, U, V, M, reps);
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 9, 1>("64x128 reg nt-load BP1024", c, U, V, M, reps);
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 9, 2>("64x128 reg nt-store BP1024", c, U, V, M, reps);
+                        run<GemmShape<64, 128, 16, 1, 4, 4>, 0, 9, 3>("64x128 reg nt-both BP1024", c, U, V, M, reps);
+                    }
+                    g_bp = 0;
+                }
+                else if (c.C < 128)
+                {
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 0>("128x64 reg plain (product)", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 1>("128x64 reg nt-load", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 2>("128x64 reg nt-store", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 3>("128x64 reg nt-both", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 6>, 0, 9, 0>("128x64 reg occ 6", c, U, V, M, reps);
+                    run<GemmShape<128, 128, 16, 2, 2, 3>, 0, 9, 0>("128x128 2x2 occ 3", c, U, V, M, reps);
+                    run<GemmShape<128, 128, 16, 2, 2, 3>, 0, 9, 3>("128x128 2x2 occ 3 nt-both", c, U, V, M, reps);
+                    run<GemmShape<128, 128, 16, 4, 1, 4>, 0, 9, 0>("128x128 4x1 occ 4", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 3>("128x64 glds nt-both", c, U, V, M, reps);
+                    g_bp = 1024;
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 0>("128x64 reg plain BP1024", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 3>("128x64 reg nt-both BP1024", c, U, V, M, reps);
+                    g_bp = 0;
+                }
+                else
+                {
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds plain (product)", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 1>("128x64 glds nt V loads", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 2>("128x64 glds nt M stores", c, U, V, M, reps);
+                    run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 3>("128x64 glds nt both", c, U, V, M, reps);
+                }
+            }
+            continue;
+        }
         if (getenv("GEMM_96"))
         {
             if (c.C < 128) continue;

@@ -69,22 +69,6 @@ __device__ __forceinline__ void stg4_nt(float* p, float4 v)
     w.w = v.w;
     __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
 }
-// experiment forms of the same store: write-through (`sc1`: the line is dropped from the XCD's L2) with or without `nt`
-template <int MODE> // 4: sc1, 6: sc1 nt, 8: sc0 sc1
-__device__ __forceinline__ void stg4_asm(float* p, float4 v)
-{
-    f32x4 w;
-    w.x = v.x;
-    w.y = v.y;
-    w.z = v.z;
-    w.w = v.w;
-    if constexpr (MODE == 4)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-    else if constexpr (MODE == 6)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(w) : "memory");
-    else
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
-}
 // 16-byte stores of ACTIVATIONS (layer outputs).  FHIP_ACT_NT is a mask of the kernel families whose output stores carry `nt`:
 // 1 = implicit-GEMM / streamed 1x1 convolutions, 2 = the staged Winograd output transform, 4 = depthwise kernels, 8 = the band-staged
 // depthwise + pointwise kernel (measured per build with tools/variant_ab.sh).

@@ -161,9 +161,7 @@ __global__ __launch_bounds__(256, BK == 16 ? OCC : 3) void wino_gemm_glds_kernel
             const int m = mrow + q * 8;
             if (m < prm.K)
             {
-                if constexpr ((NT & ~3) != 0)
-                    stg4_asm<(NT & ~1)>(mbase + (size_t)m * prm.Lm.bp, v);
-                else if constexpr (NT & 2)
+                if constexpr (NT & 2)
                     stg4_nt(mbase + (size_t)m * prm.Lm.bp, v);
                 else
                     *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;
@@ -271,9 +269,7 @@ __global__ __launch_bounds__(256, 5) void wino_gemm_glds96_kernel(const WinoGemm
             const int m = mrow + q * 8;
             if (m < prm.K)
             {
-                if constexpr ((NT & ~3) != 0)
-                    stg4_asm<(NT & ~1)>(mbase + (size_t)m * prm.Lm.bp, v);
-                else if constexpr ((NT & 2) != 0)
+                if constexpr ((NT & 2) != 0)
                     stg4_nt(mbase + (size_t)m * prm.Lm.bp, v);
                 else
                     *reinterpret_cast<float4*>(mbase + (size_t)m * prm.Lm.bp) = v;

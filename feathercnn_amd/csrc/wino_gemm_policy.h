@@ -64,9 +64,7 @@ struct WinoGemmPolicyT
         __device__ void put4(const Params& p, int m, float4 v) const
         {
             if (m >= p.K) return; // Pp is a multiple of the column tile
-            if constexpr ((NT & ~3) != 0)
-                stg4_asm<(NT & ~1)>(base + (size_t)m * p.Lm.bp, v);
-            else if constexpr (NT & 2)
+            if constexpr (NT & 2)
                 stg4_nt(base + (size_t)m * p.Lm.bp, v);
             else
                 *reinterpret_cast<float4*>(base + (size_t)m * p.Lm.bp) = v;
@@ -77,12 +75,15 @@ struct WinoGemmPolicyT
 };
 
 // Cache policy of the M stores, by the size of M (winograd_tile_gemm): FHIP_M_NT_BIG for an M of at least FHIP_M_NT_BYTES, else FHIP_M_NT_SMALL
-// (0 plain, 2 `nt`, 4 `sc1` write-through, 6 `sc1 nt`).  Round 5, tools/variant_ab.sh: see DESIGN.md 3.10.
+// (0 plain, 2 `nt`).  Round 5, tools/variant_ab.sh: an M of hundreds of MB cannot stay in any cache until the next launch
+// reads it -- `nt` stores take 1.5 - 2.5 % off the MFMA-bound launches and 3 - 7 % off the HBM-bound ones (C = 64) -- while a small M (ResNet-50:
+// <= 105 MB) written `nt` makes the output transform that reads it 6 - 13 % slower.  Write-through (`sc1`) stores measured no better than `nt`
+// (inline asm: needs hand-placed wait states, and without them corrupted M; buffer stores with per-lane bases: 15 - 90 % slower) and are not kept.
 #ifndef FHIP_M_NT_BIG
 #define FHIP_M_NT_BIG 2
 #endif
 #ifndef FHIP_M_NT_SMALL
-#define FHIP_M_NT_SMALL 4
+#define FHIP_M_NT_SMALL 0
 #endif
 // V loads of the register-staged kernel (K <= 64, or C < 128: one row tile covers all of K, so every V element is read by exactly one block)
 #ifndef FHIP_V_NT_ONCE

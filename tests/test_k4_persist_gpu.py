@@ -14,11 +14,13 @@ from oracle import conv_geom, nerr, synth
 pytestmark = pytest.mark.gpu
 
 
-def _layer(cuda, c, k, h, batch, act=1, bias=True):
+def _layer(cuda, c, k, h, batch, act=1, bias=True, wb=None):
     from feathercnn_amd import ConvLayer, ConvParam
     from feathercnn_amd.booster import WINOGRADF63
     g = conv_geom(c, k, h, 3, 1, 1, act=act, bias=int(bias))
     x, w, b = synth(g, batch, seed=c + k + h)
+    if wb is not None:  # the same filters and bias as another batch size (synth draws the input first, so its weights depend on the batch)
+        w, b = wb
     p = ConvParam(output_channels=k, input_channels=c, input_h=h, input_w=h, kernel_h=3, kernel_w=3, stride_h=1, stride_w=1, pad_left=1, pad_right=1,
                   pad_top=1, pad_bottom=1, group=1, bias_term=bias, activation=act, batch=batch)
     return g, x, w, b, p, ConvLayer(p, torch.from_numpy(w).to(cuda), torch.from_numpy(b).to(cuda) if bias else None, algo=WINOGRADF63)
@@ -30,7 +32,7 @@ def _layer(cuda, c, k, h, batch, act=1, bias=True):
 def test_persistent_output_transform_equals_one_shot_bit_for_bit(cuda, c, k, h, big, small, act, bias):
     g, x, w, b, p, layer = _layer(cuda, c, k, h, big, act, bias)
     got = layer.Forward(torch.from_numpy(x).to(cuda)).cpu().numpy()
-    _, _, _, _, ps, small_layer = _layer(cuda, c, k, h, small, act, bias)
+    _, _, _, _, ps, small_layer = _layer(cuda, c, k, h, small, act, bias, wb=(w, b))
     parts = [small_layer.Forward(torch.from_numpy(x[i:i + small]).to(cuda)).cpu().numpy() for i in range(0, big, small)]
     assert np.array_equal(got, np.concatenate(parts))
     n = min(big, 4)
@@ -44,7 +46,7 @@ def test_persistent_output_transform_with_fused_pooling(cuda):
     lib = _lib.load_library()
     c, k, h, big, small = 32, 64, 56, 64, 4
     g, x, w, b, p, layer = _layer(cuda, c, k, h, big)
-    _, _, _, _, ps, small_layer = _layer(cuda, c, k, h, small)
+    _, _, _, _, ps, small_layer = _layer(cuda, c, k, h, small, wb=(w, b))
 
     def pooled(lyr, prm, xs):
         n = xs.shape[0]

@@ -802,7 +802,14 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"bench: --gpus {n} without a launcher: starting {n} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
+    # rank 0's JSON line is the ONLY thing this process prints on stdout; whatever else the ranks or their libraries write there (gloo's
+    # connection notes in the one-GPU rehearsal, for one) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        out = sys.stdout if line.startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
+    return proc.wait()
 
 
 def main():

@@ -7,7 +7,8 @@ images/s summed.  This helper
   * loads the model ONCE (LoadParam / LoadWeights / Init + one forward), then fork()s the P workers: the weights and packed kernels
     are shared copy-on-write, so P processes do not hold P copies of a 550 MB model (the round-2 leg spent its time and the host's
     memory bandwidth on exactly that);
-  * sweeps P over an ascending list, each worker doing 1 untimed warm-up + `reps` (>= 3) individually timed forwards
+  * sweeps P over an ascending list, each worker doing 1 untimed warm-up, then -- behind a start line all P workers wait at, so that the timed
+    forwards really run P at a time -- `reps` (>= 3) individually timed forwards
     (clock_gettime inside the shim, like the reference's helper.cpp:89-98);  aggregate(P) = sum over workers of 1 / mean(times);
   * stops the sweep when the next P would not fit the time budget (predicted from the previous P), or when the aggregate has fallen
     under half of the best so far (past the knee more processes only thrash the memory system), and says which were skipped; a worker
@@ -27,13 +28,18 @@ import sys
 import time
 
 
-def worker(ref, core, reps, deadline, wfd):
+def worker(ref, core, reps, deadline, wfd, ready_w, go_r):
     try:
         os.sched_setaffinity(0, {core})
     except OSError:
         pass
     try:
-        secs = ref.time_each(1, 1)  # the untimed warm-up (it also takes this process's copy-on-write page faults) + the first timed forward
+        ref.time_each(1, 0)  # the untimed warm-up (it also takes this process's copy-on-write page faults)
+        # start line: every worker reports in and waits until all P have warmed up, so that the TIMED forwards of all workers run at the same
+        # time (fork()ing 256 workers takes seconds: without the line the first ones would time their forwards on a nearly idle host)
+        os.write(ready_w, b"r")
+        os.read(go_r, 1)  # returns (EOF) when the parent closes the write end
+        secs = ref.time_each(0, 1)
         while len(secs) < reps and time.monotonic() < deadline:
             secs += ref.time_each(0, 1)
         os.write(wfd, struct.pack(f"<i{len(secs)}d", len(secs), *secs))
@@ -56,14 +62,29 @@ def run_procs(ref, cores, procs, reps, deadline):
     passes; never fewer than one) -> list of per-worker time lists, wall seconds."""
     pipes = []
     t0 = time.perf_counter()
+    ready_r, ready_w = os.pipe()
+    go_r, go_w = os.pipe()
     for k in range(procs):
         r, w = os.pipe()
         pid = os.fork()
         if pid == 0:
             os.close(r)
-            worker(ref, cores[k % len(cores)], reps, deadline, w)
+            os.close(go_w)  # only the parent may hold the write end: closing it releases everybody
+            os.close(ready_r)
+            worker(ref, cores[k % len(cores)], reps, deadline, w, ready_w, go_r)
         os.close(w)
         pipes.append((pid, r))
+    os.close(ready_w)
+    os.close(go_r)
+    got = 0
+    while got < procs:  # all warmed up (a worker that died closes its end: EOF ends the wait)
+        chunk = os.read(ready_r, procs - got)
+        if not chunk:
+            break
+        got += len(chunk)
+    os.close(ready_r)
+    t_go = time.perf_counter()
+    os.close(go_w)  # the start line
     out = []
     for pid, r in pipes:
         head = read_exact(r, 4)
@@ -72,6 +93,7 @@ def run_procs(ref, cores, procs, reps, deadline):
         os.waitpid(pid, 0)
         if body:
             out.append(list(struct.unpack(f"<{len(body) // 8}d", body)))
+    run_procs.timed_wall = time.perf_counter() - t_go  # wall time of the timed part (all workers, from the start line)
     return out, time.perf_counter() - t0
 
 
@@ -114,7 +136,8 @@ def main():
             skipped.append(p)
             continue
         means = [sum(t) / len(t) for t in times]
-        sweep.append({"procs": p, "images_per_s": round(sum(1.0 / m for m in means), 3), "mean_forward_s": round(sum(means) / len(means), 4),
+        sweep.append({"procs": p, "images_per_s": round(sum(1.0 / m for m in means), 3),
+                      "wall_images_per_s": round(sum(len(t) for t in times) / run_procs.timed_wall, 3), "mean_forward_s": round(sum(means) / len(means), 4),
                       "best_forward_s": round(min(min(t) for t in times), 4), "timed_forwards_per_worker": min(len(t) for t in times),
                       "wall_s": round(wall, 2)})
         prev = (p, wall)
@@ -130,7 +153,8 @@ def main():
         times, wall = run_procs(ref, cores, ncpu, 1, time.monotonic())
         if len(times) == ncpu:
             means = [sum(t) / len(t) for t in times]
-            nproc_point = {"procs": ncpu, "images_per_s": round(sum(1.0 / m for m in means), 3), "mean_forward_s": round(sum(means) / len(means), 4),
+            nproc_point = {"procs": ncpu, "images_per_s": round(sum(1.0 / m for m in means), 3),
+                           "wall_images_per_s": round(sum(len(t) for t in times) / run_procs.timed_wall, 3), "mean_forward_s": round(sum(means) / len(means), 4),
                            "best_forward_s": round(min(min(t) for t in times), 4), "timed_forwards_per_worker": min(len(t) for t in times),
                            "wall_s": round(wall, 2), "outside_sweep": True}
     ref.close()

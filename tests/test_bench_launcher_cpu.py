@@ -28,21 +28,27 @@ def test_gpus_flag_and_world_size_must_agree():
     assert out.returncode != 0 and "must agree" in out.stderr
 
 
-def test_launch_command_is_the_contract_command(monkeypatch):
+def test_launch_command_is_the_contract_command(monkeypatch, capsys):
     """launch_ranks builds exactly the driver contract's command line (torch.distributed.run, one node, N ranks, 127.0.0.1)."""
     sys.path.insert(0, ROOT)
     import bench
     seen = {}
 
-    def fake_call(cmd, env=None):
-        seen["cmd"], seen["env"] = cmd, env
-        return 0
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(["[Gloo] Rank 0 is connected\n", '{"n_gpus": 2}\n'])
+
+        def wait(self):
+            return 0
 
     import subprocess as sp
-    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(sp, "Popen", FakeProc)
     monkeypatch.setenv("FHIP_BENCH_SHARE_GPU", "1")
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
     assert bench.launch_ranks(2) == 0
+    out = capsys.readouterr()
+    assert out.out == '{"n_gpus": 2}\n' and "[Gloo]" in out.err  # only the JSON line reaches stdout
     c = seen["cmd"]
     assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in c
     assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "2", "--steps", "3"]

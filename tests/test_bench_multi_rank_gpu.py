@@ -55,8 +55,8 @@ def test_bench_gpus_flag_starts_the_ranks_itself(cuda):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-steady", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]  # the launcher's stdout is rank 0's JSON line and nothing else
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert r["shard_check"]["ok"] and r["weight_broadcast"]["bytes"] == len(model_zoo.MODELS["vgg16"]()[1])

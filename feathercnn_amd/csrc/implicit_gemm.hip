@@ -25,6 +25,8 @@ size_t depthwise_packed_floats(const fhip_conv_param& p, size_t* w12_offset); //
 
 using ConvShapeBig = GemmShape<128, 64, 16, 2, 2>;
 using ConvShapeSmallM = GemmShape<64, 128, 16, 1, 4>;
+// (Bounding the register allocation for 6 blocks per CU instead of the 5 that 86 - 96 registers give -- 80 registers, 44 - 132 bytes of scratch per
+// lane -- was measured in round 5: ResNet-50 b64 14 847 -> 13 804 img/s.  EXPERIMENTS.md A8.)
 // A 64x64 tile (GemmShape<64, 64, 16, 2, 2, 8>: 4x the blocks, 8 blocks per CU) was measured against split-K on ResNet-50's
 // under-filled layers and made no difference (C1024->K256 @14 b64: 0.093 vs 0.092 ms; C256->K64 @56: 0.077 vs 0.075): not kept.
 

@@ -89,6 +89,10 @@ struct WinoGemmPolicyT
 #ifndef FHIP_V_NT_ONCE
 #define FHIP_V_NT_ONCE 1
 #endif
+// ... and only for a V of at least this many bytes (a smaller V may still be in the memory-side cache, where the transform before just wrote it)
+#ifndef FHIP_V_NT_BYTES
+#define FHIP_V_NT_BYTES 0u
+#endif
 #ifndef FHIP_M_NT_BYTES
 #define FHIP_M_NT_BYTES (150u << 20)
 #endif

@@ -1187,12 +1187,17 @@ int winograd_input_from_first(const fhip_conv_param& first, const fhip_conv_para
 template <int NT>
 static void wino_tile_gemm_launch(WinoGemmPolicy::Params& g, int columns, hipStream_t s)
 {
+    const bool v_nt = FHIP_V_NT_ONCE && (size_t)g.batches * g.C * g.Pp * sizeof(float) >= (size_t)FHIP_V_NT_BYTES;
     if (wino_small_m(g.K))
     {
         g.m_tiles = g.Kp / WinoShapeSmallM::BM;
         g.n_tiles = ceil_div(columns, WinoShapeSmallM::BN); // Pp is a multiple of every BN: no pure-padding tiles
-        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicyT<NT | FHIP_V_NT_ONCE>>), dim3(g.batches * g.m_tiles * g.n_tiles),
-                           dim3(WinoShapeSmallM::THREADS), 0, s, g);
+        if (v_nt)
+            hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicyT<NT | 1>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                               dim3(WinoShapeSmallM::THREADS), 0, s, g);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeSmallM, WinoGemmPolicyT<NT>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                               dim3(WinoShapeSmallM::THREADS), 0, s, g);
         return;
     }
     g.m_tiles = g.Kp / WinoShapeBig::BM;
@@ -1212,8 +1217,11 @@ static void wino_tile_gemm_launch(WinoGemmPolicy::Params& g, int columns, hipStr
         else
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT>), dim3(tiles), dim3(256), 0, s, g);
     }
+    else if (v_nt)
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicyT<NT | 1>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+                           dim3(WinoShapeBig::THREADS), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicyT<NT | FHIP_V_NT_ONCE>>), dim3(g.batches * g.m_tiles * g.n_tiles),
+        hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicyT<NT>>), dim3(g.batches * g.m_tiles * g.n_tiles),
                            dim3(WinoShapeBig::THREADS), 0, s, g);
 }
 

@@ -26,7 +26,12 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   cpu_baseline : the REAL reference runtime (oracle/_ref: FeatherCNN's feather::Net + AVX2 booster compiled from /root/reference)
                  on this host, one single-thread process per core (its AVX Winograd is single-thread only), one image each.
 Multi-GPU: the batch dimension is sharded; the model is generated on rank 0 and its .bin broadcast once over RCCL/xGMI, every
-rank runs its own Init; there is no steady-state collective.
+rank runs its own Init; there is no steady-state collective.  `python bench.py --gpus N` without a launcher starts its N ranks itself
+(launch_ranks: re-execution under torch.distributed.run, rank 0's JSON line is the only stdout); under a launcher --gpus must equal
+WORLD_SIZE.  A node with fewer than N GPUs is refused (FHIP_BENCH_SHARE_GPU=1: one-GPU rehearsal over gloo).
+Where to look first: `config.other_nets` (ResNet-50 b64, MobileNet-V1 b256, ResNet-50 with 512 images: images/s + the fraction of each hot
+kernel) and `roofline.also` repeat, inside the two objects every consumer keeps, what `nets` / `rooflines` hold in full;
+`nets.resnet50_global512.expected_from_1gpu` states config 5's expected strong-scaling efficiency from the one-GPU figures.
 """
 from __future__ import annotations
 

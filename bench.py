@@ -185,7 +185,9 @@ def net_cpu_baseline(net_name, model, procs, budget=30.0):
                       f"1 image per process; model loaded once, then P fork()ed single-thread workers pinned to distinct cores (weights shared "
                       f"copy-on-write; the reference's AVX Winograd is single-thread only); {r['warmup']} warm-up + {r['reps']} timed forwards "
                       f"per worker, aggregate = sum of 1 / mean forward time; best of the sweep P = {[s_['procs'] for s_ in r['sweep']]}"
-                      + (f" (P = {r['skipped']} not run: time cap {r['budget_s']:.0f}s or aggregate already under half of the best)" if r["skipped"] else "")
+                      + (f" (P = {r['skipped']} not run in the sweep: time cap {r['budget_s']:.0f}s or aggregate already under half of the best)" if r["skipped"] else "")
+                      + (f"; P = nproc = {r['nproc_point']['procs']} run once outside the sweep (nproc_point: 1 warm-up + 1 timed forward per worker)"
+                         if (r.get("nproc_point") or {}).get("outside_sweep") else "")
                       + f"; {r['sweep_s']:.1f}s sweep + {r['load_s']:.1f}s load, {wall:.1f}s wall",
             "sweep": r["sweep"], "single_core_images_per_s": one["images_per_s"] if one else None, "cpu_model": r["cpu_model"],
             "host_cores": r["host_cores"],

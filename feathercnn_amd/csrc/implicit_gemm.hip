@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "gemm_core.h"
 #include "conv_gemm_policy.h"
@@ -540,14 +541,20 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
 #define FHIP_SMALLC_LAUNCH(TM_, P_)                                                                                               \
     do                                                                                                                            \
     {                                                                                                                             \
-        static bool attr_set[64] = {false}; /* dynamic LDS above 64 KB must be allowed once per kernel AND device */              \
+        /* dynamic LDS above 64 KB must be allowed once per kernel AND device: one std::once_flag per device (threads of one process  */ \
+        /* drive different devices, tests/cpp/multi_gpu_main.cpp); devices beyond the table set the attribute on every launch         */ \
+        static std::once_flag attr_once[64];                                                                                      \
+        static hipError_t attr_err[64];                                                                                           \
         int dev_ = 0;                                                                                                             \
         FHIP_CHECK_HIP(hipGetDevice(&dev_));                                                                                      \
-        if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_])                                                                            \
+        auto set_ = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<TM_, P_>),                  \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); };                   \
+        if (dev_ < 0 || dev_ >= 64)                                                                                               \
+            FHIP_CHECK_HIP(set_());                                                                                               \
+        else                                                                                                                      \
         {                                                                                                                         \
-            FHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<TM_, P_>),                        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));                          \
-            if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;                                                                    \
+            std::call_once(attr_once[dev_], [&] { attr_err[dev_] = set_(); });                                                    \
+            FHIP_CHECK_HIP(attr_err[dev_]);                                                                                       \
         }                                                                                                                         \
         hipLaunchKernelGGL((conv_smallc_kernel<TM_, P_>), dim3(grid), dim3(256), lds, s, q);                                      \
     } while (0)

@@ -1217,7 +1217,7 @@ static void wino_tile_gemm_launch(WinoGemmPolicy::Params& g, int columns, hipStr
         else
             hipLaunchKernelGGL((wino_gemm_glds_kernel<2, 16, 6, NT>), dim3(tiles), dim3(256), 0, s, g);
     }
-    else if (v_nt)
+    else if (v_nt && g.m_tiles == 1) // only while one row tile covers all of K: with more, every V element is read by m_tiles blocks and must stay cached
         hipLaunchKernelGGL((gemm_mfma_kernel<WinoShapeBig, WinoGemmPolicyT<NT | 1>>), dim3(g.batches * g.m_tiles * g.n_tiles),
                            dim3(WinoShapeBig::THREADS), 0, s, g);
     else

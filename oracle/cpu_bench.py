@@ -38,12 +38,19 @@ def worker(ref, core, reps, deadline, wfd, ready_w, go_r):
         # start line: every worker reports in and waits until all P have warmed up, so that the TIMED forwards of all workers run at the same
         # time (fork()ing 256 workers takes seconds: without the line the first ones would time their forwards on a nearly idle host)
         os.write(ready_w, b"r")
+        os.close(ready_w)  # every worker drops its write end as soon as it has reported: the parent's EOF then means "all reported or died"
+        ready_w = -1
         os.read(go_r, 1)  # returns (EOF) when the parent closes the write end
         secs = ref.time_each(0, 1)
         while len(secs) < reps and time.monotonic() < deadline:
             secs += ref.time_each(0, 1)
         os.write(wfd, struct.pack(f"<i{len(secs)}d", len(secs), *secs))
     finally:
+        if ready_w >= 0:  # died before reporting in (exception in the warm-up): close the end so the parent does not wait for this worker
+            try:
+                os.close(ready_w)
+            except OSError:
+                pass
         os._exit(0)
 
 
@@ -77,7 +84,15 @@ def run_procs(ref, cores, procs, reps, deadline):
     os.close(ready_w)
     os.close(go_r)
     got = 0
-    while got < procs:  # all warmed up (a worker that died closes its end: EOF ends the wait)
+    # all warmed up.  A worker closes its write end right after reporting (or when it dies, OOM kill included), so EOF here means "every
+    # worker has reported or is gone"; the select timeout is the belt to that brace (a worker stuck in its warm-up past the deadline)
+    import select
+    limit = max(deadline - time.monotonic(), 0.0) + 120.0
+    t_wait = time.monotonic()
+    while got < procs:
+        left = limit - (time.monotonic() - t_wait)
+        if left <= 0 or not select.select([ready_r], [], [], left)[0]:
+            break
         chunk = os.read(ready_r, procs - got)
         if not chunk:
             break

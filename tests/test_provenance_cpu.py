@@ -47,7 +47,7 @@ def test_tree_head_prefers_git_and_believes_a_stamp_only_while_it_matches(tmp_pa
 
 
 def test_attach_traffic_only_for_the_running_tree(tmp_path, monkeypatch):
-    import bench
+    from benchkit import roofs as bench
     from feathercnn_amd import provenance
     fp = provenance.source_fingerprint()
     prof = tmp_path / "profiles"

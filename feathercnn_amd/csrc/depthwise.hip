@@ -561,37 +561,59 @@ static inline size_t dw_flat_lds_bytes(int hh, int cp, int stride = 0)
     return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13 + ((hh == 7 && stride == 1) ? cp * 49 : 0)) * sizeof(float);
 }
 
-// does the flat kernel take this geometry?  3x3, pad 1 on every side, stride 1 / 2, square planes of 7, 14 or 28 pixels
+// Plane sizes the flat kernel is instantiated for (round 6: any square plane of at most 36 pixels that the benchmark nets produce at 160 ... 288-pixel
+// inputs -- MobileNet-V1: 20 / 10 / 5, 24 / 12 / 6, 28 / 14 / 7, 32 / 16 / 8, 36 / 18 / 9 -- instead of the three literals 7 / 14 / 28: at 160 pixels
+// the nine depthwise layers behind conv5 took 570 us on the direct / chunk kernels against 370 us at equal pixels per step on 224-pixel inputs,
+// tools/res_layers.py).  X(H) lists them once: the launcher's switch and the applicability test are generated from it.
+#define FHIP_DW_FLAT_SIZES(X) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(14) X(16) X(18) X(20) X(24) X(28) X(32) X(36)
+// planes per chunk: the measured optima for 28 / 14 / 7 pixels (tools/dw_bench.hip), ~3 100 (stride 1) / ~3 900 (stride 2) floats of planes for the
+// other sizes (what the measured ones have); a multiple of 4 planes where H * H is not a multiple of 4 floats; at most 84 (a block's taps are
+// requested by lanes 0 .. 3 * cp - 1, one float4 each)
+constexpr int dw_flat_cp(int h, int stride)
+{
+    if (h == 28) return stride == 1 ? 4 : 5;
+    if (h == 14) return stride == 1 ? 15 : 20;
+    if (h == 7) return 36; // 252 row items
+    int cp = (stride == 1 ? 3136 : 3920) / (h * h);
+    if ((h * h) % 4) cp = cp / 4 * 4;
+    return cp < 1 ? 1 : (cp > 84 ? 84 : cp);
+}
+constexpr int dw_flat_unr(int h, int stride) { return (dw_flat_cp(h, stride) * h * h / 4 + 255) / 256; }
+
+// does the flat kernel take this geometry?  3x3, pad 1 on every side, stride 1 / 2, square planes of a size in FHIP_DW_FLAT_SIZES
 static inline bool dw_flat_applicable(const DwParams& q, int pad_right, int pad_bottom)
 {
+    bool size_ok = false;
+#define FHIP_X(H_) size_ok = size_ok || q.H == H_;
+    FHIP_DW_FLAT_SIZES(FHIP_X)
+#undef FHIP_X
     return q.KH == 3 && q.KW == 3 && q.SH == q.SW && (q.SH == 1 || q.SH == 2) && q.PL == 1 && q.PT == 1 && pad_right == 1 && pad_bottom == 1 &&
-           q.H == q.W && (q.H == 7 || q.H == 14 || q.H == 28);
+           q.H == q.W && size_ok;
 }
 
-// launch the flat kernel on `grid` persistent blocks with chunks of `cp` planes (cp * H*W % 4 == 0, cp <= 85, cp * H*W <= 6 * 1024)
-static inline void dw_flat_launch(const DwParams& q, int cp, int grid, hipStream_t s) // cp % 4 == 0 for 7 x 7 planes
+// launch the flat kernel on `grid` persistent blocks with chunks of dw_flat_cp planes
+static inline void dw_flat_launch(const DwParams& q, int grid, hipStream_t s)
 {
-    cp = std::min(cp, 84); // a block's taps are requested by lanes 0 .. 3 * cp - 1 (one float4 each)
-    const int chunks = ceil_div(q.planes, cp);
-    const int unr = ceil_div(cp * q.H * q.W / 4, 256);
-    const size_t lds = dw_flat_lds_bytes(q.H, cp, q.SH);
-    grid = std::min(grid, chunks);
-#define FHIP_FLAT_U(H_, S_, U_) hipLaunchKernelGGL((depthwise3x3_flat_kernel<H_, S_, U_>), dim3(grid), dim3(256), lds, s, q, cp, chunks)
-#define FHIP_FLAT(H_, S_)                        \
-    switch (unr)                                 \
-    {                                            \
-        case 1: FHIP_FLAT_U(H_, S_, 1); break;   \
-        case 2: FHIP_FLAT_U(H_, S_, 2); break;   \
-        case 3: FHIP_FLAT_U(H_, S_, 3); break;   \
-        case 4: FHIP_FLAT_U(H_, S_, 4); break;   \
-        case 5: FHIP_FLAT_U(H_, S_, 5); break;   \
-        default: FHIP_FLAT_U(H_, S_, 6); break;  \
+#define FHIP_X(H_)                                                                                                                              \
+    case H_:                                                                                                                                    \
+    {                                                                                                                                           \
+        constexpr int cp1 = dw_flat_cp(H_, 1), cp2 = dw_flat_cp(H_, 2);                                                                         \
+        static_assert(cp1 * H_ * H_ <= 6 * 1024 && cp2 * H_ * H_ <= 6 * 1024 && dw_flat_unr(H_, 1) <= 6 && dw_flat_unr(H_, 2) <= 6, "chunk size"); \
+        static_assert(((cp1 * H_ * H_) % 4) == 0 && ((cp2 * H_ * H_) % 4) == 0, "a chunk is whole float4s");                                    \
+        const int cp = q.SH == 1 ? cp1 : cp2, chunks = ceil_div(q.planes, cp);                                                                  \
+        const size_t lds = dw_flat_lds_bytes(H_, cp, q.SH);                                                                                     \
+        if (q.SH == 1)                                                                                                                          \
+            hipLaunchKernelGGL((depthwise3x3_flat_kernel<H_, 1, dw_flat_unr(H_, 1)>), dim3(std::min(grid, chunks)), dim3(256), lds, s, q, cp, chunks); \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((depthwise3x3_flat_kernel<H_, 2, dw_flat_unr(H_, 2)>), dim3(std::min(grid, chunks)), dim3(256), lds, s, q, cp, chunks); \
+        break;                                                                                                                                  \
     }
-    if (q.H == 7) { if (q.SH == 1) { FHIP_FLAT(7, 1) } else { FHIP_FLAT(7, 2) } }
-    else if (q.H == 14) { if (q.SH == 1) { FHIP_FLAT(14, 1) } else { FHIP_FLAT(14, 2) } }
-    else { if (q.SH == 1) { FHIP_FLAT(28, 1) } else { FHIP_FLAT(28, 2) } }
-#undef FHIP_FLAT
-#undef FHIP_FLAT_U
+    switch (q.H)
+    {
+        FHIP_DW_FLAT_SIZES(FHIP_X)
+        default: break;
+    }
+#undef FHIP_X
 }
 
 // Small planes of any shape (7x7, 14x14 stride 2, 5x5 kernels ...): same chunk-of-whole-planes staging, then ONE
@@ -765,11 +787,9 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     // (conv14) takes the flat kernel's row-per-lane path: 23 us vs 49 us for the direct kernel (18 vs 37 cache-resident).
     // 112- and 56-pixel planes at stride 1 (conv2, and conv4 when it is not fused into its 1x1 layer): the band kernel, 144 vs 165 us
     // and 147 vs 181 us.
-    if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && (q.H != 7 || q.SH == 1))
-    {
-        const int cp = q.H == 28 ? (q.SH == 1 ? 4 : 5) : q.H == 14 ? (q.SH == 1 ? 15 : 20) : 36; // 7 x 7: 36 planes = 252 row items
-        dw_flat_launch(q, cp, 0x7fffffff, s);
-    }
+    // (odd planes at stride 2 -- 7 -> 4 pixels -- stay on the chunk kernel below, as measured for 7 x 7)
+    if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && ((q.H & 1) == 0 || q.SH == 1))
+        dw_flat_launch(q, 0x7fffffff, s);
     else if (dw_band_applicable(q, p.pad_right, p.pad_bottom) && planes * 7 <= 0x7fffffffLL)
         dw_band_launch(q, s);
     else if (small_plane)

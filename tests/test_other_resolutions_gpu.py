@@ -69,3 +69,29 @@ def test_fall_back_cost_is_visible(cuda, name, size, batch):
     per_pixel = rates[size] * size * size / (rates[224] * 224 * 224)
     print(f"\n{name} b{batch}: {rates[224]:.0f} img/s @224, {rates[size]:.0f} img/s @{size} = {per_pixel:.2f} of the 224-pixel rate per pixel")
     assert rates[size] > 0 and per_pixel > 0.3
+
+
+# every plane size the flat depthwise kernel is instantiated for (depthwise.hip FHIP_DW_FLAT_SIZES), both strides, with a channel count that leaves the
+# last chunk ragged and a plane count that is not a multiple of the chunk size: parity against the checker, and against the direct kernel's route on
+# a neighbouring size that is NOT in the list (a fall-back must give the same values)
+FLAT_SIZES = (5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 32, 36)
+
+
+@pytest.mark.parametrize("h", FLAT_SIZES + (11, 22))
+@pytest.mark.parametrize("stride", (1, 2))
+def test_flat_depthwise_plane_sizes(cuda, h, stride):
+    import torch
+
+    import oracle
+    from feathercnn_amd import DEPTHWISE, ConvLayer, ConvParam
+    from oracle import conv_geom, synth
+    c, batch = 37, 5  # 185 planes: never a multiple of a chunk
+    g = conv_geom(c, c, h, 3, stride, 1, group=c)
+    x, w, b = synth(g, batch, seed=h * 10 + stride)
+    p = ConvParam(output_channels=c, input_channels=c, input_h=h, input_w=h, kernel_h=3, kernel_w=3, stride_h=stride, stride_w=stride, pad_left=1,
+                  pad_right=1, pad_top=1, pad_bottom=1, group=c, bias_term=True, activation=1, batch=batch)
+    dev = torch.device("cuda:0")
+    layer = ConvLayer(p, torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), algo=DEPTHWISE)
+    y = layer.Forward(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = oracle.best().forward(g, x, w, b)
+    assert y.shape == want.shape and nerr(y, want) <= 1e-5

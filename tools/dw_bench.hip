@@ -185,17 +185,13 @@ int main(int argc, char** argv)
             vars.push_back({"band kernel", [=](int i) { dw_band_launch(at(i), 0); }});
         if (cs.H == 7 || cs.H == 14 || cs.H == 28)
         {
-            // chunk sizes whose float4 count is just under a multiple of 256 lanes
-            const std::vector<int> cps = cs.H == 28 ? std::vector<int>{4, 5, 6} : cs.H == 14 ? std::vector<int>{10, 15, 20, 26} : std::vector<int>{36, 72};
-            for (int cp : cps)
-                for (int grid : {256 * 4, 256 * 8, 1 << 30})
-                {
-                    const size_t lds = dw_flat_lds_bytes(cs.H, cp, cs.S);
-                    if (grid < (1 << 30) && (size_t)(grid / 256) * lds > 150 * 1024) continue; // would not be resident
-                    char nm[64];
-                    snprintf(nm, sizeof nm, "flat cp%d (%d KB) grid %s", cp, (int)(lds / 1024), grid == (1 << 30) ? "=chunks" : (grid == 1024 ? "4/CU" : "8/CU"));
-                    vars.push_back({nm, [=](int i) { dw_flat_launch(at(i), cp, grid, 0); }});
-                }
+            // (rounds 3 - 5 scanned the chunk size here; since round 6 it is dw_flat_cp(H, S), a compile-time function of the plane size)
+            for (int grid : {256 * 4, 256 * 8, 1 << 30})
+            {
+                char nm[64];
+                snprintf(nm, sizeof nm, "flat cp%d grid %s", dw_flat_cp(cs.H, cs.S), grid == (1 << 30) ? "=chunks" : (grid == 1024 ? "4/CU" : "8/CU"));
+                vars.push_back({nm, [=](int i) { dw_flat_launch(at(i), grid, 0); }});
+            }
         }
         {
             const long long in4 = (long long)in_n / 4, out4 = (long long)out_n / 4;

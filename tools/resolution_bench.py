@@ -35,6 +35,13 @@ def rate(name, size, steps=20, batch=None, layers=False):
     dt = time.perf_counter() - t0
     by = None
     if layers:  # eager per-layer HIP-event times, summed by layer type / route (each carries ~5 us of event overhead: compare like with like)
+        if SUB.get(name, 1) > 1:  # kernels of concurrent replicas share the chip: the per-layer pass runs the batch through a single-stream net
+            net.close()
+            net = Net(fusion=3, graph=False, tuned=True, concurrency=True, sub_batches=1)
+            net.LoadParam(p)
+            net.LoadWeights(b)
+            net.FeedInput(i, x)
+            net.Forward()
         net.set_graph(False)
         by = {}
         for _ in range(3):

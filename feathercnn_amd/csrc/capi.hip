@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface declared in include/feather_hip/feather_hip.h: algorithm selection,
 // buffer sizing, Init and Forward dispatch (the GPU counterpart of reference src/booster/avx/booster.cpp),
 // error reporting and per-stage event timing.
+#include <string.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -71,6 +72,27 @@ int device_compute_units()
         int cu = 0;
         if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
         cached[dev] = cu;
+    }
+    return cached[dev];
+}
+
+// LDS bytes of one CU of the current device (cached per device; 160 KiB on MI355X) -- what the persistent grids' residency estimates divide by
+size_t device_lds_bytes()
+{
+    static size_t cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 160 * 1024;
+    if (cached[dev] == 0)
+    {
+        // gfx950: 160 KiB by the architecture (MI355X_MICROARCH.md; some ROCm versions report the 64 KiB per-block default here).  Any other part: what the
+        // runtime says, at least the 64 KiB every CDNA CU has -- the estimates then err on the side of fewer resident blocks, never more
+        hipDeviceProp_t prop;
+        int b = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+            b = 160 * 1024;
+        else if (hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || b < 64 * 1024)
+            b = 64 * 1024;
+        cached[dev] = (size_t)b;
     }
     return cached[dev];
 }

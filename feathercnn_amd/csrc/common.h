@@ -37,6 +37,8 @@ struct StageTimer
 
 // Compute units of the current device (cached per device; 256 on MI355X).
 int device_compute_units();
+// LDS bytes per CU of the current device (cached per device; 160 KiB on MI355X): the residency estimates of the persistent grids use it
+size_t device_lds_bytes();
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -525,7 +525,7 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     const size_t lds_base = ((size_t)2 * q.kd2 * bm + q.patch_alloc) * sizeof(float) + ((size_t)2 * q.kd2) * sizeof(int);
     const size_t scr_bytes = (size_t)4 * 16 * 36 * sizeof(float);
     const int cap = q.S == 1 ? 6 : 4;
-    auto resident = [&](size_t bytes) { return (int)std::min<size_t>(cap, (size_t)(160 * 1024) / (bytes + 512)); };
+    auto resident = [&](size_t bytes) { return (int)std::min<size_t>(cap, device_lds_bytes() / (bytes + 512)); };
 #ifdef FHIP_SMALLC_NO_ALIAS
     q.epi_alias = 0;
 #else
@@ -535,7 +535,7 @@ static int smallc_forward(const fhip_conv_param& p, int batch, float* out, const
     // resident blocks per CU (the grid is persistent): as many as the LDS takes, up to 6 at stride 1 and 4 at stride 2 (tools/conv1_bench.py,
     // same box: VGG conv1_1 b32 137 / 126 / 119 / 118 us with 3 / 4 / 5 / 6, MobileNet conv1 b256 191 / 183 / 191 / 191; an XCD-contiguous
     // tile order changed nothing)
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(q.S == 1 ? 6 : 4, (size_t)(160 * 1024) / (lds + 512)));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(q.S == 1 ? 6 : 4, device_lds_bytes() / (lds + 512)));
     const int grid = (int)std::min<long long>(q.tiles, (long long)device_compute_units() * per_cu);
     const int passes = ceil_div(q.patch, 256);
 #define FHIP_SMALLC_LAUNCH(TM_, P_)                                                                                               \

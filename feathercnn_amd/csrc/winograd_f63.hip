@@ -1059,7 +1059,7 @@ static bool winograd_input_staged(const fhip_conv_param& p, int batch, const fhi
     if (nv > 7) return false;
     const size_t lds = plane_bytes * g.ppb;
     const long long units = (planes + g.ppb - 1) / g.ppb;
-    const int bpc = std::max(1, std::min((int)((160 * 1024) / lds), 12 / (int)(threads / 64)));
+    const int bpc = std::max(1, std::min((int)(device_lds_bytes() / lds), 12 / (int)(threads / 64)));
     const unsigned grid = ((unsigned)std::min<long long>(units, (long long)device_compute_units() * bpc) + 7u) & ~7u;
 #define FHIP_K2S(NV_) case NV_: hipLaunchKernelGGL((wino_input_staged_kernel<NV_>), dim3(grid), dim3(threads), lds, s, v, input, g, (int)units); break
     switch (nv)
@@ -1328,7 +1328,7 @@ int winograd_output_transform(const fhip_conv_param& p, int batch, float* output
         dim3 sgrid(ceil_div(g.units, g.UB), q.K);
         // more work items than blocks that are resident at once: persistent blocks with the next item's loads under this item's stores
         const long long items = (long long)sgrid.x * sgrid.y;
-        const int resident = device_compute_units() * (int)std::min<size_t>(kK4PersistBlocksPerCu, (160 * 1024) / lds);
+        const int resident = device_compute_units() * (int)std::min<size_t>(kK4PersistBlocksPerCu, device_lds_bytes() / lds);
         if (kK4PersistBlocksPerCu > 0 && items > resident && items <= 0x7fffffffLL && lds <= 64 * 1024)
         {
             const dim3 pgrid((unsigned)(resident + 7) & ~7u);
@@ -1420,7 +1420,7 @@ int winograd_output_to_next_input(const fhip_conv_param& p, const fhip_conv_para
     const size_t lds = plane_bytes * g.ppb;
     const long long units = (planes + g.ppb - 1) / g.ppb;
     // persistent: what is resident at 3 waves per SIMD (12 waves per CU) and 160 KB of LDS, a multiple of 8 so that every XCD runs the same count
-    const int bpc = std::max(1, std::min((int)((160 * 1024) / lds), 12 / (int)(threads / 64)));
+    const int bpc = std::max(1, std::min((int)(device_lds_bytes() / lds), 12 / (int)(threads / 64)));
     const unsigned grid = ((unsigned)std::min<long long>(units, (long long)device_compute_units() * bpc) + 7u) & ~7u;
     StageTimer tm(FHIP_STAGE_WINO_CHAIN, s);
 #define FHIP_CHAIN(B_, R_, P_)                                                                                                                       \

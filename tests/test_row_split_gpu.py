@@ -36,12 +36,13 @@ def _layer(cuda, c, k, h, batch, wb=None):
 @pytest.mark.parametrize("c,k,h,batch,small,tiles,pieces", CASES)
 def test_row_pieces_match_whole_tiles_and_the_oracle(cuda, c, k, h, batch, small, tiles, pieces):
     from feathercnn_amd import booster
-    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
-        pytest.skip("the tile counts above are remainders over 256 CUs")
     g, x, w, b, p, layer = _layer(cuda, c, k, h, batch)
     pl = booster.winograd_plan(p)
     n_tiles = -(-pl.columns // 64)
-    assert pl.frequency_points * (-(-k // 128)) * n_tiles == tiles and 0 < tiles % 256 <= 256 // pieces  # the geometry is in the class it claims
+    assert pl.frequency_points * (-(-k // 128)) * n_tiles == tiles
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert 0 < tiles % 256 <= 256 // pieces  # on the MI355X's 256 CUs the geometry is in the row-split class it claims
+    # (another CU count puts the launch in another class -- whole tiles, or other pieces: the two comparisons below hold for every class)
     got = layer.Forward(torch.from_numpy(x).to(cuda)).cpu().numpy()
     _, _, _, _, _, small_layer = _layer(cuda, c, k, h, small, wb=(w, b))
     parts = [small_layer.Forward(torch.from_numpy(np.ascontiguousarray(x[i:i + small])).to(cuda)).cpu().numpy() for i in range(0, batch, small)]

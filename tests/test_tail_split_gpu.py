@@ -62,13 +62,13 @@ def test_tail_columns_in_pieces_match_the_oracle(cuda, c, k, h, w, s, batch):
 
 @pytest.mark.parametrize("c,k,h,w,s,batch", PLAIN)
 def test_neighbouring_geometries_keep_the_plain_launch(cuda, c, k, h, w, s, batch):
-    if _cus() != 256:
-        pytest.skip("geometries chosen for 256 CUs")
     g, x, wt, b, p, layer = _layer(cuda, c, k, h, w, s, batch)
-    assert layer.buffer_bytes == 0
+    if _cus() == 256:
+        assert layer.buffer_bytes == 0  # (geometries chosen for 256 CUs; on another count they may take the tail split -- the parity below holds either way)
     if batch <= 8:
         want = oracle.best().forward(g, x, wt, b)
-        got = layer.Forward(torch.from_numpy(x).to(cuda)).cpu().numpy()
+        scratch = torch.empty(max(layer.buffer_bytes // 4, 64), device=cuda)
+        got = layer.Forward(torch.from_numpy(x).to(cuda), scratch=scratch).cpu().numpy()
         assert nerr(got, want) <= 1e-5
 
 

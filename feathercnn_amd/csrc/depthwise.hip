@@ -308,6 +308,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_chunk_kernel(const DwParams 
 //   * the four results leave as one 16-byte store of the contiguous output stream.
 // Against the direct kernel (lane = VX x R patch: 7 or 3 lanes per image row, 8-byte loads, three runtime integer divisions per
 // item) and the generic chunk kernel above (per-output decode with runtime divisions, 18 LDS reads per output): tools/dw_bench.hip.
+// the row-per-lane path of the flat kernel: small odd planes at stride 1 (a second LDS image holds the results)
+constexpr bool dw_flat_row_path(int h, int stride) { return (h & 1) && h <= 9 && stride == 1; }
+
 template <int HH, int S, int UNR>
 __global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kernel(const DwParams q, int chunk_planes, int chunks)
 {
@@ -358,36 +361,39 @@ __global__ __launch_bounds__(256, FHIP_DW_FLAT_MINW) void depthwise3x3_flat_kern
         if (chunk + (int)gridDim.x < chunks) FHIP_DW_REQUEST(chunk + (int)gridDim.x)
         const int nout = np * OHW;
         float* const obase = q.out + (size_t)plane0 * OHW; // 16-byte aligned
-        if constexpr (HH == 7 && S == 1)
+        if constexpr (dw_flat_row_path(HH, S))
         {
-            // 7 x 7 planes (49 floats: groups of four outputs straddle rows AND planes).  A lane owns one whole image row: 3 x 7 LDS
-            // dwords, column validity known at compile time, the 7 results go to a second LDS image and leave as 16-byte stores.
-            float* const otile = bl + chunk_planes; // [chunk_planes][49]
-            for (int it = tid; it < np * 7; it += 256)
+            // small odd planes at stride 1 -- 7 x 7 (49 floats; round 3), 5 x 5 and 9 x 9 (round 6) --: groups of four outputs straddle rows AND planes.
+            // A lane owns one whole image row: 3 x HH LDS dwords, column validity known at compile time, the HH results go to a second LDS image
+            // and leave as 16-byte stores.
+            float* const otile = bl + chunk_planes; // [chunk_planes][HW]
+            for (int it = tid; it < np * HH; it += 256)
             {
-                const int pl = it / 7, y = it - pl * 7;
+                const int pl = it / HH, y = it - pl * HH;
                 const float4* w4 = reinterpret_cast<const float4*>(wl + pl * 12);
                 const float4 wa = w4[0], wb = w4[1], wc = w4[2];
                 const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
                 const float bias = bl[pl];
-                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float acc[HH];
+#pragma unroll
+                for (int x = 0; x < HH; ++x) acc[x] = 0.f;
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
                 {
                     const int yy = y + m - 1;
-                    const bool rowok = (unsigned)yy < 7u;
-                    const float* row = tile + pl * 49 + min(max(yy, 0), 6) * 7;
-                    float r[7];
+                    const bool rowok = (unsigned)yy < (unsigned)HH;
+                    const float* row = tile + pl * HW + min(max(yy, 0), HH - 1) * HH;
+                    float r[HH];
 #pragma unroll
-                    for (int x = 0; x < 7; ++x) r[x] = rowok ? row[x] : 0.f;
+                    for (int x = 0; x < HH; ++x) r[x] = rowok ? row[x] : 0.f;
 #pragma unroll
-                    for (int x = 0; x < 7; ++x)
+                    for (int x = 0; x < HH; ++x)
 #pragma unroll
                         for (int n = 0; n < 3; ++n)
-                            if (x + n - 1 >= 0 && x + n - 1 < 7) acc[x] += r[x + n - 1] * w[m * 3 + n];
+                            if (x + n - 1 >= 0 && x + n - 1 < HH) acc[x] += r[x + n - 1] * w[m * 3 + n];
                 }
 #pragma unroll
-                for (int x = 0; x < 7; ++x) otile[it * 7 + x] = apply_act(acc[x] + bias, q.relu);
+                for (int x = 0; x < HH; ++x) otile[it * HH + x] = apply_act(acc[x] + bias, q.relu);
             }
             __syncthreads();
             const int n4o = nout >> 2;
@@ -557,8 +563,8 @@ static inline void dw_band_launch(const DwParams& q, hipStream_t s)
 static inline size_t dw_flat_lds_bytes(int hh, int cp, int stride = 0)
 {
     const int pad = (hh + 1 + 3) / 4 * 4;
-    // 7 x 7 stride 1: a second image for the results (cp * 13 floats of taps + bias is a multiple of 4 floats when cp % 4 == 0)
-    return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13 + ((hh == 7 && stride == 1) ? cp * 49 : 0)) * sizeof(float);
+    // row-per-lane path (5 / 7 / 9 pixels, stride 1): a second image for the results (cp * 13 floats of taps + bias is a multiple of 4 floats when cp % 4 == 0)
+    return (size_t)(pad + cp * hh * hh + pad + 4 + cp * 13 + (dw_flat_row_path(hh, stride) ? cp * hh * hh : 0)) * sizeof(float);
 }
 
 // Plane sizes the flat kernel is instantiated for (round 6: any square plane of at most 36 pixels that the benchmark nets produce at 160 ... 288-pixel

@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256, 4) void wino_input_from_first_kernel(const Win
 // 267 us fused; in the net conv1_1 + conv1_2 0.881 -> 0.805 ms.  The kernel is vector-ALU bound: 2.5 k VALU instructions per (tile,
 // channel) -- 1728 FMAs + the two butterflies -- against a 2.4 k floor, the SIMDs issue VALU 64 % of the launch (PMC: SQ_ACTIVE_INST_VALU),
 // v_pk_fma_f32 pairs ran no faster than scalar v_fmac, and neither 8 waves per block nor hoisting / sinking the LDS reads moves it.
+#ifndef FHIP_FIRST_ORDER
+#define FHIP_FIRST_ORDER 0 // block order of wino_input_from_first_staged_kernel: 0 channel group slowest, 1 tile block slowest (measurement switch)
+#endif
 constexpr int kFirstCpb = 16;   // output channels per block, 4 per wave (tools/first_bench.hip: 16 / 32 / 64 -> 322 / 332 / 358 us)
 constexpr int kFirstStage = 12; // image loads a thread keeps in flight while staging
 constexpr int kFirstWaves = 4;  // waves per block (8 waves at 128 registers spill: 392 us)
@@ -187,7 +190,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void wino_input_from_first_s
     // consecutive tile blocks on the same XCD: their 256-byte V runs share cache lines at both ends (p = n T + t is 16-byte aligned at
     // best), which only merge into whole-line writes inside one L2
     const int lin = XCD ? xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+#if FHIP_FIRST_ORDER == 1
+    // tile blocks slowest, channel groups fastest: the gridDim.y blocks that read the SAME image rows are neighbours in an XCD's walk, so the rows come
+    // over the fabric once and from that XCD's L2 gridDim.y - 1 times (round 6; with the channel group slowest an XCD walks one channel group over
+    // ALL images: rocprofv3 counted 883 MB per launch for 776 algorithmic -- VGG-16 b32: the 19 MB image fetched gridDim.y = 4 times over plus halos)
+    const int bx = lin / gridDim.y, by = lin - bx * gridDim.y;
+#else
     const int bx = lin % gridDim.x, by = lin / gridDim.x;
+#endif
     const int n = bx / q.bpi, b = bx - n * q.bpi;
     const int t0 = b * TPB, nt = min(TPB, q.T - t0);
     const int ty0 = t0 / q.TX, ty1 = (t0 + nt - 1) / q.TX;

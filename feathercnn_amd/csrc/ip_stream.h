@@ -69,6 +69,14 @@ __global__ __launch_bounds__(256) void ip_pack_input_kernel(float* __restrict__ 
     }
 }
 
+#ifndef FHIP_IP_NT
+#define FHIP_IP_NT 0 // 1: the weight image is requested with the non-temporal hint (every float4 of it is read once per call); measurement switch
+#endif
+#if FHIP_IP_NT
+#define FHIP_IP_LDW(p) __builtin_nontemporal_load(p)
+#else
+#define FHIP_IP_LDW(p) (*(p))
+#endif
 #define FHIP_IP_MFMA4(A, B)                                                  \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B).x, acc0, 0, 0, 0); \
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B).y, acc1, 0, 0, 0); \
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void ip_stream_kernel(const IpStreamParams p)
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
         {
-            av[u] = a[(size_t)u * 64];
+            av[u] = FHIP_IP_LDW(a + (size_t)u * 64);
             bv[u] = b[(size_t)u * 64];
         }
         for (int t = 1; t < trips; ++t)
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void ip_stream_kernel(const IpStreamParams p)
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
             {
-                an[u] = a[(size_t)u * 64];
+                an[u] = FHIP_IP_LDW(a + (size_t)u * 64);
                 bn[u] = b[(size_t)u * 64];
             }
 #pragma unroll
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void ip_stream_kernel(const IpStreamParams p)
     }
     for (int u = 0; u < tail; ++u)
     {
-        const f32x4 a1 = a[(size_t)u * 64], b1 = b[(size_t)u * 64];
+        const f32x4 a1 = FHIP_IP_LDW(a + (size_t)u * 64), b1 = b[(size_t)u * 64];
         FHIP_IP_MFMA4(a1, b1);
     }
     // C/D layout: column (batch index) = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -538,25 +538,37 @@ __global__ __launch_bounds__(256) void depthwise3x3_band_kernel(const DwParams q
     }
 }
 
-// does the band kernel take this geometry?  3x3, stride 1, pad 1 on every side, square planes of 112 or 56 pixels
+// Plane sizes the band kernel is instantiated for: X(W, RB, UNR) -- 112 / 56 pixels (round 3: MobileNet-V1's conv2 / conv4 at 224-pixel inputs) and, round 6,
+// the stride-1 planes above the flat kernel's range that the nets produce at 160 ... 288-pixel inputs (40 / 48 / 64 / 72 / 80 / 96 / 128 / 144).  RB output rows
+// per band: (RB + 2) * W / 4 float4 requests fit UNR per lane, RB divides the plane (or the last band is ragged).
+#define FHIP_DW_BAND_SIZES(X) X(144, 12, 2) X(128, 16, 3) X(112, 16, 2) X(96, 16, 2) X(80, 20, 2) X(72, 24, 2) X(64, 32, 3) X(56, 28, 2) X(48, 24, 2) X(40, 40, 2)
+
+// does the band kernel take this geometry?  3x3, stride 1, pad 1 on every side, square planes of a size in FHIP_DW_BAND_SIZES
 static inline bool dw_band_applicable(const DwParams& q, int pad_right, int pad_bottom)
 {
-    return q.KH == 3 && q.KW == 3 && q.SH == 1 && q.SW == 1 && q.PL == 1 && q.PT == 1 && pad_right == 1 && pad_bottom == 1 && q.H == q.W &&
-           (q.H == 112 || q.H == 56);
+    bool size_ok = false;
+#define FHIP_X(W_, RB_, U_) size_ok = size_ok || q.H == W_;
+    FHIP_DW_BAND_SIZES(FHIP_X)
+#undef FHIP_X
+    return q.KH == 3 && q.KW == 3 && q.SH == 1 && q.SW == 1 && q.PL == 1 && q.PT == 1 && pad_right == 1 && pad_bottom == 1 && q.H == q.W && size_ok;
 }
 
 static inline void dw_band_launch(const DwParams& q, hipStream_t s)
 {
-    if (q.H == 112)
-    {
-        // 16-row bands: 18 x 112 floats = 504 float4 (2 requests per lane), 7 bands per plane
-        hipLaunchKernelGGL((depthwise3x3_band_kernel<112, 16, 2>), dim3((unsigned)q.planes * 7u), dim3(256), 0, s, q, 7);
+#define FHIP_X(W_, RB_, U_)                                                                                                                   \
+    case W_:                                                                                                                                  \
+    {                                                                                                                                         \
+        static_assert((RB_ + 2) * (W_ / 4) <= 256 * U_ && W_ % 4 == 0, "a band's rows are U_ float4 requests per lane");                      \
+        constexpr int bands = (W_ + RB_ - 1) / RB_;                                                                                           \
+        hipLaunchKernelGGL((depthwise3x3_band_kernel<W_, RB_, U_>), dim3((unsigned)q.planes * (unsigned)bands), dim3(256), 0, s, q, bands); \
+        break;                                                                                                                                \
     }
-    else
+    switch (q.H)
     {
-        // 56 x 56: 28-row bands: 30 x 56 floats = 420 float4, 2 bands per plane
-        hipLaunchKernelGGL((depthwise3x3_band_kernel<56, 28, 2>), dim3((unsigned)q.planes * 2u), dim3(256), 0, s, q, 2);
+        FHIP_DW_BAND_SIZES(FHIP_X)
+        default: break;
     }
+#undef FHIP_X
 }
 
 // LDS bytes of the flat kernel for a chunk of `cp` planes of HH x HH
@@ -796,7 +808,7 @@ int depthwise_forward(const fhip_conv_param& p, int batch, float* out, const flo
     // (odd planes at stride 2 -- 7 -> 4 pixels -- stay on the chunk kernel below, as measured for 7 x 7)
     if (dw_flat_applicable(q, p.pad_right, p.pad_bottom) && ((q.H & 1) == 0 || q.SH == 1))
         dw_flat_launch(q, 0x7fffffff, s);
-    else if (dw_band_applicable(q, p.pad_right, p.pad_bottom) && planes * 7 <= 0x7fffffffLL)
+    else if (dw_band_applicable(q, p.pad_right, p.pad_bottom) && planes * 12 <= 0x7fffffffLL)
         dw_band_launch(q, s);
     else if (small_plane)
     {

@@ -95,3 +95,23 @@ def test_flat_depthwise_plane_sizes(cuda, h, stride):
     y = layer.Forward(torch.from_numpy(x).to(dev)).cpu().numpy()
     want = oracle.best().forward(g, x, w, b)
     assert y.shape == want.shape and nerr(y, want) <= 1e-5
+
+
+# every plane size the band depthwise kernel is instantiated for (depthwise.hip FHIP_DW_BAND_SIZES), stride 1, plus two neighbours that are not (direct kernel)
+@pytest.mark.parametrize("h", (40, 48, 56, 64, 72, 80, 96, 112, 128, 144, 44, 100))
+def test_band_depthwise_plane_sizes(cuda, h):
+    import torch
+
+    import oracle
+    from feathercnn_amd import DEPTHWISE, ConvLayer, ConvParam
+    from oracle import conv_geom, synth
+    c, batch = 5, 3
+    g = conv_geom(c, c, h, 3, 1, 1, group=c)
+    x, w, b = synth(g, batch, seed=h)
+    p = ConvParam(output_channels=c, input_channels=c, input_h=h, input_w=h, kernel_h=3, kernel_w=3, stride_h=1, stride_w=1, pad_left=1, pad_right=1,
+                  pad_top=1, pad_bottom=1, group=c, bias_term=True, activation=1, batch=batch)
+    dev = torch.device("cuda:0")
+    layer = ConvLayer(p, torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), algo=DEPTHWISE)
+    y = layer.Forward(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = oracle.best().forward(g, x, w, b)
+    assert y.shape == want.shape and nerr(y, want) <= 1e-5

@@ -153,3 +153,14 @@ def test_convstack_line():
     line, _ = report.compose(head, {}, args=dict(ARGS, mode="convstack"), world=1, cpu={"value": None, "error": "boom"}, tree=TREE)
     r = _check_line(report.fit_line(line), 1)
     assert "conv stack" in r["metric"] and r["cpu_baseline"] == {"value": None, "error": "boom"}
+
+
+def test_only_the_cpu_baseline_leg_touches_the_oracle():
+    """bench.py may use oracle/ in its cpu_baseline leg only: of benchkit's modules exactly cpu.py imports it, bench.py itself does not."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    hits = [f for f in sorted(os.listdir(os.path.join(root, "benchkit"))) if f.endswith(".py") and pat.search(open(os.path.join(root, "benchkit", f)).read())]
+    assert hits == ["cpu.py"]
+    assert not pat.search(open(os.path.join(root, "bench.py")).read())

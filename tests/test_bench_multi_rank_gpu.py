@@ -107,3 +107,21 @@ def test_bench_gpus_flag_must_agree_with_the_launcher(cuda):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True, timeout=300,
                          env=env, cwd=ROOT)
     assert out.returncode != 0 and "must agree" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_line_is_compact_and_complete(cuda, tmp_path):
+    """The N = 1 form of the driver's command (shortened: headline net only, no CPU leg): ONE stdout line of at most 8 KiB that json.loads, with the contract keys,
+    `roofline` carrying the spread of its 7 attribution passes, and everything long in the detail side file the line names."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FHIP_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--headline-only", "--no-steady", "--no-cpu-baseline"]
+    out, detail = _run(cmd, env, tmp_path)
+    r = _line(out, only_line=True)
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["value"] > 0 and r["dtype"] == "f32" and r["vs_baseline"] is None
+    assert r["config"]["net"] == "vgg16" and r["config"]["per_gpu_batch"] == 32 and r["detail"] == detail
+    ro = r["roofline"]
+    assert ro["bound"] == "mfma" and len(ro["frac_passes"]) == 7 and ro["frac_min"] <= ro["frac"] <= ro["frac_max"] and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 2e-3
+    d = json.load(open(detail))
+    assert len(d["tables"]["vgg16"]) >= 15 and d["rooflines"]["vgg16"][0]["note"]

@@ -274,6 +274,19 @@ int main(int argc, char** argv)
             }
             continue;
         }
+        if (getenv("GEMM_REGVSGLDS"))
+        {
+            // round 6: conv2_2-class launches (C = 128: 8 k-tiles) on the register-staged main loop against the LDS-DMA kernel the product picks from 8 k-tiles on
+            if (c.C != 128) continue;
+            for (int round = 0; round < 3; ++round)
+            {
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 2>("128x64 glds nt M (product)", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 2>("128x64 reg nt M", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 9, 3>("128x64 reg nt M + nt V", c, U, V, M, reps);
+                run<GemmShape<128, 64, 16, 2, 2, 4>, 0, 3, 0>("128x64 glds plain", c, U, V, M, reps);
+            }
+            continue;
+        }
         if (getenv("GEMM_128"))
         {
             // round 6: the LDS-DMA kernel with a 128 x 128 tile (tools/experiments/wino_gemm_glds128.h) against the product's launch, MFMA-bound shapes only
